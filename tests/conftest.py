@@ -1,0 +1,48 @@
+"""pytest configuration: markers + import paths.
+
+`-m "not gpu"` : oracle vs golden vectors, host logic, C-ABI symbol export (no GPU needed).
+`-m gpu`       : parity tests proper -- HIP path (through the C-ABI) vs oracle / goldens.
+"""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "hybrid-ode-for-glp-1-and-glucose_amd")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with gpurun)")
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return GOLDEN
+
+
+@pytest.fixture(scope="session")
+def g0():
+    import numpy as np
+    w = np.load(os.path.join(GOLDEN, "g0_weights_h64_l4.npz"))
+    return {"nn": w["nn_flat"], "ode": w["ode"], "H": 64, "L": 4, "raw": w}
+
+
+@pytest.fixture(scope="session")
+def g0_small():
+    import numpy as np
+    w = np.load(os.path.join(GOLDEN, "g0_weights_h32_l2.npz"))
+    return {"nn": w["nn_flat"], "ode": w["ode"], "H": 32, "L": 2}
+
+
+def has_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
