@@ -1,0 +1,99 @@
+// hode_capi.hip -- extern "C" entry points of libhode.so (declared in include/hode.h).
+// Plain pointers and sizes only; argument validation happens here, on the host, BEFORE any
+// launch: a kernel is never started on shapes it was not compiled for.
+#include "hode_kernels.h"
+#include "hode_device.h"
+
+using namespace hode;
+
+namespace {
+
+inline bool mode_ok(int mode, const void *p) { return mode == 0 || (p != nullptr && (mode == 1 || mode == 2)); }
+
+template <typename R>
+int solve_fwd(void *stream, int B, int T, const R *x0, const R *t, int t_batched, const R *meal, int meal_mode,
+              const R *tvns, int tvns_mode, const R *gd, int gd_mode, const R *ode_p, const R *nn_p, int n_sets,
+              int H, int L, int method, double rtol, double atol, int max_steps, R *y, int32_t *status,
+              int32_t *nsteps, int32_t *nfev, void *tape)
+{
+    if (B < 0 || T < 1 || !x0 || !t || !ode_p || !nn_p || !y || !status) return HODE_EINVAL;
+    if (!mode_ok(meal_mode, meal) || !mode_ok(tvns_mode, tvns) || !mode_ok(gd_mode, gd)) return HODE_EINVAL;
+    if (n_sets < 1 || (B % n_sets) != 0 || max_steps < 1) return HODE_EINVAL;
+    if (method != HODE_METHOD_DP54 && method != HODE_METHOD_RK4) return HODE_EINVAL;
+    if (!(rtol >= 0) || !(atol >= 0) || (method == HODE_METHOD_DP54 && rtol == 0 && atol == 0)) return HODE_EINVAL;
+    if (H < 1 || H > HODE_MAX_HIDDEN || L < 1 || L > HODE_MAX_LAYERS) return HODE_EUNSUPPORTED;
+    if (B == 0) return HODE_OK;
+    SolveArgs<R> a;
+    a.B = B; a.T = T; a.t_batched = t_batched ? 1 : 0;
+    a.meal_mode = meal_mode; a.tvns_mode = tvns_mode; a.gd_mode = gd_mode;
+    a.n_sets = n_sets; a.H = H; a.P = nn_param_count(H, L); a.max_steps = max_steps;
+    a.x0 = x0; a.t = t; a.meal = meal; a.tvns = tvns; a.gd = gd; a.ode_p = ode_p; a.nn_p = nn_p;
+    a.rtol = (R)rtol; a.atol = (R)atol;
+    a.y = y; a.status = status; a.nsteps = nsteps; a.nfev = nfev;
+    a.tape = (R *)tape;
+    a.tape_seg = tape ? (int32_t *)((char *)tape + (size_t)B * max_steps * 8 * sizeof(R)) : nullptr;
+    return launch_solve_fwd<R>((hipStream_t)stream, a, L, method);
+}
+
+template <typename R>
+int rhs_fwd(void *stream, int B, const R *x, const R *t, const R *meal, const R *tvns, const R *gd, const R *ode_p,
+            const R *nn_p, int H, int L, R *out)
+{
+    if (B < 0 || !x || !ode_p || !nn_p || !out) return HODE_EINVAL;
+    if (H < 1 || H > HODE_MAX_HIDDEN || L < 1 || L > HODE_MAX_LAYERS) return HODE_EUNSUPPORTED;
+    if (B == 0) return HODE_OK;
+    RhsArgs<R> a{};
+    a.B = B; a.H = H; a.P = nn_param_count(H, L);
+    a.x = x; a.t = t; a.meal = meal; a.tvns = tvns; a.gd = gd; a.ode_p = ode_p; a.nn_p = nn_p; a.out = out;
+    return launch_rhs_fwd<R>((hipStream_t)stream, a, L);
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *hode_version(void) { return "hode 0.1.0 (gfx950; wave-per-trajectory DP5(4) + adjoint)"; }
+
+int hode_nn_param_count(int H, int L) { return (H < 1 || L < 1) ? HODE_EINVAL : nn_param_count(H, L); }
+
+size_t hode_tape_bytes(int B, int max_steps, int elem_size)
+{
+    if (B < 0 || max_steps < 0 || (elem_size != 4 && elem_size != 8)) return 0;
+    return (size_t)B * (size_t)max_steps * (8 * (size_t)elem_size + sizeof(int32_t));
+}
+
+int hode_rhs_fwd_f32(void *stream, int B, const float *x, const float *t, const float *meal, const float *tvns,
+                     const float *gd, const float *ode_p, const float *nn_p, int H, int L, float *out)
+{
+    return rhs_fwd<float>(stream, B, x, t, meal, tvns, gd, ode_p, nn_p, H, L, out);
+}
+int hode_rhs_fwd_f64(void *stream, int B, const double *x, const double *t, const double *meal, const double *tvns,
+                     const double *gd, const double *ode_p, const double *nn_p, int H, int L, double *out)
+{
+    return rhs_fwd<double>(stream, B, x, t, meal, tvns, gd, ode_p, nn_p, H, L, out);
+}
+
+int hode_solve_fwd_f32(void *stream, int B, int T, const float *x0, const float *t, int t_batched, const float *meal,
+                       int meal_mode, const float *tvns, int tvns_mode, const float *gd, int gd_mode,
+                       const float *ode_p, const float *nn_p, int n_sets, int H, int L, int method, double rtol,
+                       double atol, int max_steps, float *y, int32_t *status, int32_t *nsteps, int32_t *nfev, void *tape)
+{
+    return solve_fwd<float>(stream, B, T, x0, t, t_batched, meal, meal_mode, tvns, tvns_mode, gd, gd_mode, ode_p, nn_p,
+                            n_sets, H, L, method, rtol, atol, max_steps, y, status, nsteps, nfev, tape);
+}
+int hode_solve_fwd_f64(void *stream, int B, int T, const double *x0, const double *t, int t_batched, const double *meal,
+                       int meal_mode, const double *tvns, int tvns_mode, const double *gd, int gd_mode,
+                       const double *ode_p, const double *nn_p, int n_sets, int H, int L, int method, double rtol,
+                       double atol, int max_steps, double *y, int32_t *status, int32_t *nsteps, int32_t *nfev, void *tape)
+{
+    return solve_fwd<double>(stream, B, T, x0, t, t_batched, meal, meal_mode, tvns, tvns_mode, gd, gd_mode, ode_p, nn_p,
+                             n_sets, H, L, method, rtol, atol, max_steps, y, status, nsteps, nfev, tape);
+}
+
+int hode_selftest_xlane(void *stream, int32_t *out)
+{
+    if (!out) return HODE_EINVAL;
+    return launch_selftest((hipStream_t)stream, out);
+}
+
+}  // extern "C"

@@ -1,0 +1,197 @@
+// hode_solve_fwd.hip -- K2+K3: batched forward integration, one trajectory per wavefront.
+//
+// Replaces HybridODENN.forward (reference models/hybrid_ode_nn.py:136-261): the per-patient
+// scipy.integrate.solve_ivp loop, the RHS round trip through NumPy and the input interpolation.
+// Integrator = SciPy RK45's controller (scipy/integrate/_ivp/rk.py:111-176) with every grid
+// point a mandatory step boundary (the meal forcing is piecewise linear with kinks there,
+// SURVEY.md F6/F7); FSAL derivative and step-size proposal are carried across grid points.
+// The CPU restatement of exactly this algorithm is oracle/hode_oracle_impl.h (hode_oracle_solve).
+#include "hode_device.h"
+#include "hode_kernels.h"
+
+namespace hode {
+
+template <typename R> __device__ __forceinline__ R inp_at(const R *__restrict__ p, int mode, int b, int T, int k)
+{
+    if (mode == 0) return R(0);
+    return (mode == 1) ? p[b] : p[(size_t)b * T + k];
+}
+
+template <typename R> struct Eps;
+template <> struct Eps<float> { static constexpr float v = 1.1920929e-7f; };
+template <> struct Eps<double> { static constexpr double v = 2.220446049250313e-16; };
+
+template <typename R, int NL, int METHOD, int LB>
+__global__ __launch_bounds__(64, LB) void solve_fwd_kernel(const SolveArgs<R> a)
+{
+    const int lane = threadIdx.x;
+    const int b = blockIdx.x;                 // one wave == one trajectory
+    const int T = a.T;
+    const int set = b / (a.B / a.n_sets);
+
+    MlpRegs<R, NL> W;
+    mlp_load<R, NL>(W, a.nn_p + (size_t)set * a.P, a.H, lane);
+    OdeP<R> o;
+    ode_load(o, a.ode_p + 17 * set);
+
+    const R *__restrict__ tg = a.t + (a.t_batched ? (size_t)b * T : 0);
+    R *__restrict__ yb = a.y + (size_t)b * T * 6;
+    R *__restrict__ tape = a.tape ? a.tape + (size_t)b * a.max_steps * 8 : nullptr;
+    int *__restrict__ tseg = a.tape ? a.tape_seg + (size_t)b * a.max_steps : nullptr;
+    const bool use_gd = a.gd_mode != 0;
+
+    R Y = (lane < 6) ? a.x0[(size_t)b * 6 + lane] : R(0);
+    if (lane < 6) yb[lane] = Y;
+
+    int st = HODE_ST_OK, ns = 0, nf = 0, k = 0;
+    R h_abs = R(0);
+    R K1 = R(0);
+    bool have_f = false;
+
+    for (; k + 1 < T && st == HODE_ST_OK; ++k) {
+        const R t0 = tg[k], t1 = tg[k + 1];
+        const R m0 = inp_at(a.meal, a.meal_mode, b, T, k), m1 = inp_at(a.meal, a.meal_mode, b, T, k + 1);
+        const R v0 = inp_at(a.tvns, a.tvns_mode, b, T, k), v1 = inp_at(a.tvns, a.tvns_mode, b, T, k + 1);
+        const R d0 = inp_at(a.gd, a.gd_mode, b, T, k), d1 = inp_at(a.gd, a.gd_mode, b, T, k + 1);
+        const R len = t1 - t0;
+        if (!(len > R(0))) {                  // repeated grid time: copy the state
+            if (lane < 6) yb[(size_t)(k + 1) * 6 + lane] = Y;
+            continue;
+        }
+        const R inv_len = first_lane(R(1) / len);
+        const R dm = first_lane(m1 - m0), dv = first_lane(v1 - v0), dd = first_lane(d1 - d0);
+        // piecewise-linear forcing on this interval (models/hybrid_ode_nn.py:217-229)
+        auto f_at = [&](R ts, R Ys) -> R {
+            const R al = (ts - t0) * inv_len;
+            const R gde = use_gd ? gd_effect(o, rfma(al, dd, d0)) : R(0);
+            return rhs_eval<R, NL, false>(W, o, ts, Ys, rfma(al, dm, m0), rfma(al, dv, v0), gde, lane, nullptr);
+        };
+        R tc = t0;
+
+        if constexpr (METHOD == HODE_METHOD_RK4) {
+            const R hh = len, th = t0 + R(0.5) * hh;
+            const R k1 = f_at(t0, Y);
+            const R k2 = f_at(th, rfma(R(0.5) * hh, k1, Y));
+            const R k3 = f_at(th, rfma(R(0.5) * hh, k2, Y));
+            const R k4 = f_at(t1, rfma(hh, k3, Y));
+            if (tape && ns < a.max_steps) {
+                const R e = (lane == 0) ? t0 : (lane == 1) ? hh : dpp_mov<0x112, 0xF, true>(R(0), Y);   // row_shr:2
+                if (lane < 8) tape[(size_t)ns * 8 + lane] = e;
+                if (lane == 0) tseg[ns] = k;
+            }
+            Y = rfma(hh / R(6), (k1 + R(2) * k2) + (R(2) * k3 + k4), Y);
+            nf += 4;
+            ns += 1;
+        } else {
+            if (!have_f) {
+                // first derivative + Hairer's initial step (scipy/integrate/_ivp/common.py:68-135)
+                K1 = f_at(t0, Y);
+                const R sc = (lane < 6) ? (a.atol + rabs(Y) * a.rtol) : R(1);
+                const R q0 = Y / sc, q1 = K1 / sc;
+                const float dn0 = sqrtf((float)first_lane(oct_allsum(q0 * q0)) / 6.0f);
+                const float dn1 = sqrtf((float)first_lane(oct_allsum(q1 * q1)) / 6.0f);
+                float h0 = (dn0 < 1e-5f || dn1 < 1e-5f) ? 1e-6f : 0.01f * dn0 / dn1;
+                h0 = fminf(h0, (float)len);
+                const R f1 = f_at(t0 + (R)h0, rfma((R)h0, K1, Y));
+                const R q2 = (f1 - K1) / sc;
+                const float dn2 = sqrtf((float)first_lane(oct_allsum(q2 * q2)) / 6.0f) / h0;
+                const float h1 = (dn1 <= 1e-15f && dn2 <= 1e-15f) ? fmaxf(1e-6f, h0 * 1e-3f)
+                                                                   : powf(0.01f / fmaxf(dn1, dn2), 0.2f);
+                h_abs = first_lane((R)fminf(fminf(100.0f * h0, h1), (float)len));
+                nf += 2;
+                have_f = true;
+            }
+            while (tc < t1 && st == HODE_ST_OK) {
+                bool rejected = false;
+                for (;;) {                     // scipy/integrate/_ivp/rk.py:126-176
+                    if (ns >= a.max_steps) { st = HODE_ST_MAXSTEPS; break; }
+                    const R min_step = R(10) * Eps<R>::v * (rabs(tc) > R(1e-30) ? rabs(tc) : R(1e-30));
+                    if (h_abs < min_step) { st = HODE_ST_UNDERFLOW; break; }
+                    R h = h_abs, tn = tc + h;
+                    bool clipped = false;
+                    if (tn >= t1 || (t1 - tn) < R(0.01) * h) { tn = t1; h = tn - tc; clipped = true; }
+                    h = first_lane(h);
+                    tn = first_lane(tn);
+                    using D = DP<R>;
+                    const R K2 = f_at(rfma(D::c2, h, tc), rfma(h * D::a21, K1, Y));
+                    const R K3 = f_at(rfma(D::c3, h, tc), rfma(h, D::a31 * K1 + D::a32 * K2, Y));
+                    const R K4 = f_at(rfma(D::c4, h, tc), rfma(h, D::a41 * K1 + D::a42 * K2 + D::a43 * K3, Y));
+                    const R K5 = f_at(rfma(D::c5, h, tc), rfma(h, D::a51 * K1 + D::a52 * K2 + D::a53 * K3 + D::a54 * K4, Y));
+                    const R K6 = f_at(tn, rfma(h, D::a61 * K1 + D::a62 * K2 + D::a63 * K3 + D::a64 * K4 + D::a65 * K5, Y));
+                    const R Yn = rfma(h, D::b1 * K1 + D::b3 * K3 + D::b4 * K4 + D::b5 * K5 + D::b6 * K6, Y);
+                    const R K7 = f_at(tn, Yn);
+                    nf += 6;
+                    const R err = h * (D::e1 * K1 + D::e3 * K3 + D::e4 * K4 + D::e5 * K5 + D::e6 * K6 + D::e7 * K7);
+                    const R ymax = rabs(Y) > rabs(Yn) ? rabs(Y) : rabs(Yn);
+                    const R qe = (lane < 6) ? err / (a.atol + ymax * a.rtol) : R(0);
+                    float en = sqrtf((float)first_lane(oct_allsum(qe * qe)) / 6.0f);
+                    const float ysum = (float)first_lane(oct_allsum((lane < 6) ? Yn : R(0)));
+                    if (!(en == en) || !(fabsf(ysum) <= 3.0e38f) || !(fabsf(en) <= 3.0e38f)) en = 1e30f;
+                    if (en < 1.0f) {
+                        float fac = (en == 0.0f) ? 10.0f : fminf(10.0f, 0.9f * __builtin_exp2f(-0.2f * __builtin_log2f(en)));
+                        if (rejected) fac = fminf(1.0f, fac);
+                        if (tape) {
+                            const R e = (lane == 0) ? tc : (lane == 1) ? h : dpp_mov<0x112, 0xF, true>(R(0), Y);   // row_shr:2
+                            if (lane < 8) tape[(size_t)ns * 8 + lane] = e;
+                            if (lane == 0) tseg[ns] = k;
+                        }
+                        const R hn = h * (R)fac;
+                        h_abs = first_lane((clipped && hn < h_abs) ? h_abs : hn);   // a clipped step never shrinks the proposal
+                        Y = Yn;
+                        K1 = K7;                                       // FSAL
+                        tc = tn;
+                        ns++;
+                        break;
+                    } else {
+                        h_abs = first_lane(h * (R)fmaxf(0.2f, 0.9f * __builtin_exp2f(-0.2f * __builtin_log2f(en))));
+                        rejected = true;
+                        if (en >= 1e30f && !(h_abs > min_step)) { st = HODE_ST_NONFINITE; break; }
+                    }
+                }
+            }
+        }
+        if (st == HODE_ST_OK) {
+            const float ysum = (float)first_lane(oct_allsum((lane < 6) ? Y : R(0)));
+            if (!(fabsf(ysum) <= 3.0e38f)) st = HODE_ST_NONFINITE;
+            else if (lane < 6) yb[(size_t)(k + 1) * 6 + lane] = Y;
+        }
+        if (st != HODE_ST_OK) break;
+    }
+    if (st != HODE_ST_OK) {
+        // rows from the failed interval on stay zero (models/hybrid_ode_nn.py:243-256)
+        for (int r = k + 1; r < T; ++r)
+            if (lane < 6) yb[(size_t)r * 6 + lane] = R(0);
+    }
+    if (lane == 0) {
+        a.status[b] = st;
+        if (a.nsteps) a.nsteps[b] = ns;
+        if (a.nfev) a.nfev[b] = nf;
+    }
+}
+
+template <typename R, int NL>
+static int launch_nl(hipStream_t s, const SolveArgs<R> &a, int method)
+{
+    dim3 grid(a.B), block(64);
+    if (method == HODE_METHOD_DP54)
+        hipLaunchKernelGGL((solve_fwd_kernel<R, NL, HODE_METHOD_DP54, (sizeof(R) == 4 ? 2 : 1)>), grid, block, 0, s, a);
+    else
+        hipLaunchKernelGGL((solve_fwd_kernel<R, NL, HODE_METHOD_RK4, (sizeof(R) == 4 ? 2 : 1)>), grid, block, 0, s, a);
+    return hipGetLastError() == hipSuccess ? HODE_OK : HODE_ELAUNCH;
+}
+
+template <typename R> int launch_solve_fwd(hipStream_t s, const SolveArgs<R> &a, int L, int method)
+{
+    switch (L) {
+    case 1: return launch_nl<R, 1>(s, a, method);
+    case 2: return launch_nl<R, 2>(s, a, method);
+    case 3: return launch_nl<R, 3>(s, a, method);
+    case 4: return launch_nl<R, 4>(s, a, method);
+    }
+    return HODE_EUNSUPPORTED;
+}
+
+template int launch_solve_fwd<float>(hipStream_t, const SolveArgs<float> &, int, int);
+template int launch_solve_fwd<double>(hipStream_t, const SolveArgs<double> &, int, int);
+
+}  // namespace hode

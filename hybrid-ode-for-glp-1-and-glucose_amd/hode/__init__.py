@@ -1,0 +1,9 @@
+"""hode -- Python binding of libhode.so (HIP kernels for gfx950 behind a C ABI, include/hode.h).
+
+PyTorch is plumbing here: device memory, streams, torch.distributed.  All arithmetic of the hot
+path (RHS, DP5(4) stepping, adjoint, Adam) runs in the hand-written HIP kernels; there is NO
+CPU / eager fallback -- if the library or a GPU is missing the calls raise.
+"""
+from . import _capi as capi  # noqa: F401
+from ._capi import (METHOD_DP54, METHOD_RK4, HodeError, lib_path, load, n_params, solve_fwd, rhs_fwd,  # noqa: F401
+                    selftest_xlane, version)

@@ -1,0 +1,160 @@
+"""ctypes binding of the C ABI declared in include/hode.h.  Tensors in, tensors out (device memory
+owned by torch's allocator, work enqueued on torch's current stream)."""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libhode.so")
+_lib = None
+
+METHOD_DP54 = 0
+METHOD_RK4 = 1
+
+ST_OK, ST_MAXSTEPS, ST_UNDERFLOW, ST_NONFINITE = 0, 1, 2, 3
+_ERR = {-1: "HODE_EINVAL (bad argument)", -2: "HODE_EUNSUPPORTED (shape outside compiled range: H<=64, L<=4)",
+        -3: "HODE_ELAUNCH (HIP launch failed)"}
+
+# every symbol include/hode.h declares (tests check that the library exports all of them)
+SYMBOLS = ["hode_version", "hode_nn_param_count", "hode_tape_bytes", "hode_rhs_fwd_f32", "hode_rhs_fwd_f64",
+           "hode_rhs_bwd_f32", "hode_rhs_bwd_f64", "hode_solve_fwd_f32", "hode_solve_fwd_f64",
+           "hode_solve_bwd_f32", "hode_solve_bwd_f64", "hode_adam_step_f32", "hode_mse_fwd_bwd_f32",
+           "hode_selftest_xlane"]
+
+
+class HodeError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return _SO
+
+
+def load():
+    """Load libhode.so.  Raises (loudly) when it has not been built: there is no fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            raise HodeError(f"{_SO} not found: build it with `python __graft_entry__.py` "
+                            "(hipcc --offload-arch=gfx950); there is no CPU fallback for the hot path")
+        _lib = C.CDLL(_SO)
+        _lib.hode_version.restype = C.c_char_p
+        _lib.hode_tape_bytes.restype = C.c_size_t
+        _lib.hode_tape_bytes.argtypes = [C.c_int, C.c_int, C.c_int]
+    return _lib
+
+
+def version():
+    return load().hode_version().decode()
+
+
+def n_params(H, L):
+    return 9 * H + H + (L - 1) * (H * H + H) + 6 * H + 6
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise HodeError(f"{what} failed: {_ERR.get(rc, rc)}")
+
+
+def _need_gpu(t):
+    if not t.is_cuda:
+        raise HodeError("hode kernels need tensors on a HIP device (no CPU fallback)")
+
+
+def _ptr(t):
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _sfx(dtype):
+    if dtype == torch.float32:
+        return "f32"
+    if dtype == torch.float64:
+        return "f64"
+    raise HodeError(f"unsupported dtype {dtype}")
+
+
+def _prep(t, dtype, dev):
+    return None if t is None else t.to(device=dev, dtype=dtype).contiguous()
+
+
+def _mode(t, B, T):
+    """models/hybrid_ode_nn.py:217-231: dim()==2 time varying [B,T]; dim()==1 constant [B]."""
+    if t is None:
+        return 0
+    if t.dim() == 2:
+        if tuple(t.shape) != (B, T):
+            raise HodeError(f"time-varying input must be [B,T]=({B},{T}), got {tuple(t.shape)}")
+        return 2
+    if tuple(t.shape) != (B,):
+        raise HodeError(f"constant input must be [B]=({B},), got {tuple(t.shape)}")
+    return 1
+
+
+def selftest_xlane(device="cuda"):
+    out = torch.zeros(64 * 12, dtype=torch.int32, device=device)
+    _check(load().hode_selftest_xlane(_stream(), _ptr(out)), "hode_selftest_xlane")
+    return out.view(64, 12)
+
+
+def rhs_fwd(x, t, meal, tvns, gd, ode_p, nn_p, H, L):
+    _need_gpu(x)
+    dt, dev = x.dtype, x.device
+    x = x.contiguous()
+    B = x.shape[0]
+    t, meal, tvns, gd = (_prep(v, dt, dev) for v in (t, meal, tvns, gd))
+    ode_p, nn_p = _prep(ode_p, dt, dev), _prep(nn_p, dt, dev)
+    assert nn_p.numel() == n_params(H, L) and ode_p.numel() == 17
+    out = torch.empty(B, 6, dtype=dt, device=dev)
+    fn = getattr(load(), f"hode_rhs_fwd_{_sfx(dt)}")
+    _check(fn(_stream(), C.c_int(B), _ptr(x), _ptr(t), _ptr(meal), _ptr(tvns), _ptr(gd), _ptr(ode_p), _ptr(nn_p),
+              C.c_int(H), C.c_int(L), _ptr(out)), "hode_rhs_fwd")
+    return out
+
+
+class Solve:
+    """Result of solve_fwd: trajectories + per-trajectory diagnostics (+ tape for the adjoint)."""
+    __slots__ = ("y", "status", "nsteps", "nfev", "tape", "max_steps", "ctx")
+
+
+def solve_fwd(x0, t, meal, tvns, gd, ode_p, nn_p, H, L, method=METHOD_DP54, rtol=1e-6, atol=1e-8,
+              max_steps=None, n_sets=1, want_tape=False):
+    _need_gpu(x0)
+    dt, dev = x0.dtype, x0.device
+    x0 = x0.contiguous()
+    B = x0.shape[0]
+    t = _prep(t, dt, dev)
+    T = t.shape[-1]
+    t_batched = int(t.dim() == 2)
+    if t_batched and t.shape[0] != B:
+        raise HodeError("batched time grid must be [B,T]")
+    meal, tvns, gd = (_prep(v, dt, dev) for v in (meal, tvns, gd))
+    ode_p, nn_p = _prep(ode_p, dt, dev), _prep(nn_p, dt, dev)
+    if nn_p.numel() != n_sets * n_params(H, L) or ode_p.numel() != 17 * n_sets:
+        raise HodeError("parameter vector size does not match (H, L, n_sets)")
+    if max_steps is None:
+        max_steps = (T - 1) if method == METHOD_RK4 else 8 * (T - 1) + 64
+    s = Solve()
+    s.y = torch.empty(B, T, 6, dtype=dt, device=dev)
+    s.status = torch.empty(B, dtype=torch.int32, device=dev)
+    s.nsteps = torch.empty(B, dtype=torch.int32, device=dev)
+    s.nfev = torch.empty(B, dtype=torch.int32, device=dev)
+    s.max_steps = max_steps
+    s.tape = None
+    if want_tape:
+        nbytes = load().hode_tape_bytes(B, max_steps, x0.element_size())
+        s.tape = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    fn = getattr(load(), f"hode_solve_fwd_{_sfx(dt)}")
+    rc = fn(_stream(), C.c_int(B), C.c_int(T), _ptr(x0), _ptr(t), C.c_int(t_batched),
+            _ptr(meal), C.c_int(_mode(meal, B, T)), _ptr(tvns), C.c_int(_mode(tvns, B, T)),
+            _ptr(gd), C.c_int(_mode(gd, B, T)), _ptr(ode_p), _ptr(nn_p), C.c_int(n_sets), C.c_int(H), C.c_int(L),
+            C.c_int(method), C.c_double(rtol), C.c_double(atol), C.c_int(max_steps), _ptr(s.y), _ptr(s.status),
+            _ptr(s.nsteps), _ptr(s.nfev), _ptr(s.tape))
+    _check(rc, "hode_solve_fwd")
+    s.ctx = (t, t_batched, meal, tvns, gd, ode_p, nn_p, n_sets, H, L, method)
+    return s

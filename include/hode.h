@@ -1,0 +1,140 @@
+/*
+ * hode.h -- C ABI of libhode.so: batched hybrid-ODE (6-state GLP-1/glucose RHS + MLP residual)
+ * integration and adjoint on AMD MI355X (gfx950).
+ *
+ * This is the drop-in boundary for ONE path of OliverDOU776/Hybrid-ODE-for-GLP-1-and-Glucose.
+ * The reference has no FFI of its own (pure Python): each entry point
+ * below names the reference Python it replaces.  Citations are relative to the reference root.
+ *
+ * Conventions
+ *   - every pointer is DEVICE memory owned by the caller, contiguous row-major, 16-byte aligned
+ *     where noted; nothing is allocated, freed or kept by the callee;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); all work is enqueued
+ *     on it, nothing synchronises, so calls may be captured into a hipGraph;
+ *   - return value: 0 ok, HODE_EINVAL bad argument, HODE_EUNSUPPORTED shape outside the
+ *     kernels' compiled range, HODE_ELAUNCH HIP launch error.  Integration failures are NEVER
+ *     a return code: they are per-trajectory values in `status[B]`
+ *     (reference: models/hybrid_ode_nn.py:243-256 logs a warning and zero-fills);
+ *   - flat MLP parameter vector `nn_p` = PyTorch parameters() order of NNResidual.network
+ *     (models/nn_residual.py:59-78):  W1[H,9] b1[H] (W[H,H] b[H])x(L-1) Wout[6,H] bout[6];
+ *   - `ode_p[17]` = ODECore buffers in registration order (models/ode_core.py:44-71):
+ *     a_GI k_I rho G_b I_b E_max EC_50 Glu_b V_max K_m k_L k_GE0 IGD_50 g p_7 p_8 p_9;
+ *   - input "mode" of meal / tvns / gd (models/hybrid_ode_nn.py:217-231):
+ *     0 absent (=0), 1 constant per patient [B], 2 time-varying on the grid [B,T] (lerp);
+ *   - parameter sets: the B trajectories are n_sets equal contiguous groups, group s uses
+ *     ode_p + 17*s and nn_p + P*s (n_sets = 1: one shared set; >1: VI samples / Sobol sets,
+ *     inference/vi.py:88-100, plots/plot_all.py:171-196).  B % n_sets must be 0.
+ */
+#ifndef HODE_H
+#define HODE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HODE_OK 0
+#define HODE_EINVAL (-1)
+#define HODE_EUNSUPPORTED (-2)
+#define HODE_ELAUNCH (-3)
+
+/* integrator (hybrid_ode_nn.py:174-181 maps names to SciPy; 'rk45' == DP5(4)) */
+#define HODE_METHOD_DP54 0 /* adaptive Dormand-Prince 5(4), grid points are step boundaries */
+#define HODE_METHOD_RK4 1  /* classic RK4, one step per grid interval (BASELINE config 1)   */
+
+/* per-trajectory status */
+#define HODE_ST_OK 0
+#define HODE_ST_MAXSTEPS 1  /* accepted-step budget (max_steps) exhausted */
+#define HODE_ST_UNDERFLOW 2 /* step size below 10 ulp(t) (scipy rk.py:128-129) */
+#define HODE_ST_NONFINITE 3 /* state became non-finite */
+
+#define HODE_MAX_HIDDEN 64 /* MLP width compiled for (one hidden unit per wavefront lane) */
+#define HODE_MAX_LAYERS 4  /* hidden layers compiled for */
+
+const char *hode_version(void);
+
+/* number of MLP parameters for (H hidden, L hidden layers); 13510 for (64,4) */
+int hode_nn_param_count(int H, int L);
+
+/* bytes of one tape entry / of the whole tape the solve writes for the adjoint */
+size_t hode_tape_bytes(int B, int max_steps, int elem_size /* 4 or 8 */);
+
+/* ---- K1: RHS forward.  Replaces HybridODENN.ode_residual (models/hybrid_ode_nn.py:108-134)
+ *      = ODECore.forward (models/ode_core.py:81-166) + NNResidual.forward
+ *      (models/nn_residual.py:100-151).  t/meal/tvns/gd: [B] or NULL.  out[B,6].            */
+int hode_rhs_fwd_f32(void *stream, int B, const float *x, const float *t, const float *meal,
+                     const float *tvns, const float *gd, const float *ode_p, const float *nn_p,
+                     int H, int L, float *out);
+int hode_rhs_fwd_f64(void *stream, int B, const double *x, const double *t, const double *meal,
+                     const double *tvns, const double *gd, const double *ode_p, const double *nn_p,
+                     int H, int L, double *out);
+
+/* ---- K5: RHS backward (VJP).  Replaces torch autograd over ode_residual in the physics loss
+ *      (models/hybrid_ode_nn.py:318-330).  gout[B,6] -> gx[B,6] (written), gt[B] (written, may
+ *      be NULL), gnn[P] and gode[17] (ACCUMULATED with atomics: zero them first; may be NULL). */
+int hode_rhs_bwd_f32(void *stream, int B, const float *x, const float *t, const float *meal,
+                     const float *tvns, const float *gd, const float *ode_p, const float *nn_p,
+                     int H, int L, const float *gout, float *gx, float *gt, float *gnn, float *gode);
+int hode_rhs_bwd_f64(void *stream, int B, const double *x, const double *t, const double *meal,
+                     const double *tvns, const double *gd, const double *ode_p, const double *nn_p,
+                     int H, int L, const double *gout, double *gx, double *gt, double *gnn, double *gode);
+
+/* ---- K2+K3: forward solve.  Replaces HybridODENN.forward (models/hybrid_ode_nn.py:136-261):
+ *      the per-patient scipy.integrate.solve_ivp loop (:184-256) incl. input interpolation
+ *      (:210-231) and the RK45 stepper (scipy/integrate/_ivp/rk.py:14-72,111-176).
+ *      t: [T] (t_batched=0) or [B,T] (t_batched=1).  y[B,T,6] written (rows after a failure
+ *      are zero).  status/nsteps/nfev: int32[B] (nsteps/nfev may be NULL).
+ *      tape: NULL, or hode_tape_bytes(B,max_steps,sizeof(real)) bytes that receive the accepted
+ *      steps (needed by hode_solve_bwd_*).                                                      */
+int hode_solve_fwd_f32(void *stream, int B, int T, const float *x0, const float *t, int t_batched,
+                       const float *meal, int meal_mode, const float *tvns, int tvns_mode,
+                       const float *gd, int gd_mode, const float *ode_p, const float *nn_p,
+                       int n_sets, int H, int L, int method, double rtol, double atol,
+                       int max_steps, float *y, int32_t *status, int32_t *nsteps, int32_t *nfev,
+                       void *tape);
+int hode_solve_fwd_f64(void *stream, int B, int T, const double *x0, const double *t, int t_batched,
+                       const double *meal, int meal_mode, const double *tvns, int tvns_mode,
+                       const double *gd, int gd_mode, const double *ode_p, const double *nn_p,
+                       int n_sets, int H, int L, int method, double rtol, double atol,
+                       int max_steps, double *y, int32_t *status, int32_t *nsteps, int32_t *nfev,
+                       void *tape);
+
+/* ---- K4: reverse-time discrete adjoint of the solve above (no reference counterpart: the
+ *      reference detaches the solve; north_star requires it).
+ *      gy[B,T,6] = dLoss/dy  ->  gx0[B,6] (written), gnn[n_sets,P] and gode[n_sets,17]
+ *      (ACCUMULATED with atomics: zero them first; either may be NULL).                        */
+int hode_solve_bwd_f32(void *stream, int B, int T, const float *t, int t_batched,
+                       const float *meal, int meal_mode, const float *tvns, int tvns_mode,
+                       const float *gd, int gd_mode, const float *ode_p, const float *nn_p,
+                       int n_sets, int H, int L, int method, int max_steps, const int32_t *nsteps,
+                       const int32_t *status, const void *tape, const float *gy, float *gx0,
+                       float *gnn, float *gode);
+int hode_solve_bwd_f64(void *stream, int B, int T, const double *t, int t_batched,
+                       const double *meal, int meal_mode, const double *tvns, int tvns_mode,
+                       const double *gd, int gd_mode, const double *ode_p, const double *nn_p,
+                       int n_sets, int H, int L, int method, int max_steps, const int32_t *nsteps,
+                       const int32_t *status, const void *tape, const double *gy, double *gx0,
+                       double *gnn, double *gode);
+
+/* ---- K6: fused global-norm clip + Adam.  Replaces clip_grad_norm_(...,5.0) + torch.optim.Adam
+ *      .step() (train/train_hybrid.py:255-261, 438-441).  g is first multiplied by grad_scale
+ *      (e.g. 1/world_size after an all-reduce(sum)); max_norm <= 0 disables clipping.
+ *      scratch: >= 8 bytes of device memory (holds the squared norm), zeroed by the call.       */
+int hode_adam_step_f32(void *stream, int64_t n, float *p, const float *g, float *m, float *v,
+                       float lr, float beta1, float beta2, float eps, int step, float max_norm,
+                       float grad_scale, float weight_decay, void *scratch);
+
+/* ---- loss helper: sum((y - obs)^2) and dLoss/dy = 2*scale*(y-obs) in one pass
+ *      (models/hybrid_ode_nn.py:294 F.mse_loss).  loss_sum: double[1], ACCUMULATED.            */
+int hode_mse_fwd_bwd_f32(void *stream, int64_t n, const float *y, const float *obs, float scale,
+                         double *loss_sum, float *gy);
+
+/* ---- self test of the cross-lane primitives (DPP / permlane swaps); out: int32[64*8].        */
+int hode_selftest_xlane(void *stream, int32_t *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HODE_H */
