@@ -48,6 +48,44 @@ int rhs_fwd(void *stream, int B, const R *x, const R *t, const R *meal, const R 
     return launch_rhs_fwd<R>((hipStream_t)stream, a, L);
 }
 
+template <typename R>
+int solve_bwd(void *stream, int B, int T, const R *t, int t_batched, const R *meal, int meal_mode, const R *tvns,
+              int tvns_mode, const R *gd, int gd_mode, const R *ode_p, const R *nn_p, int n_sets, int H, int L,
+              int method, int max_steps, const int32_t *nsteps, const int32_t *status, const void *tape, const R *gy,
+              R *gx0, R *gnn, R *gode)
+{
+    if (B < 0 || T < 1 || !t || !ode_p || !nn_p || !nsteps || !status || !tape || !gy || !gx0) return HODE_EINVAL;
+    if (!mode_ok(meal_mode, meal) || !mode_ok(tvns_mode, tvns) || !mode_ok(gd_mode, gd)) return HODE_EINVAL;
+    if (n_sets < 1 || (B % n_sets) != 0 || max_steps < 1) return HODE_EINVAL;
+    if (method != HODE_METHOD_DP54 && method != HODE_METHOD_RK4) return HODE_EINVAL;
+    if (H < 1 || H > HODE_MAX_HIDDEN || L < 1 || L > HODE_MAX_LAYERS) return HODE_EUNSUPPORTED;
+    if (B == 0) return HODE_OK;
+    AdjArgs<R> a;
+    a.B = B; a.T = T; a.t_batched = t_batched ? 1 : 0;
+    a.meal_mode = meal_mode; a.tvns_mode = tvns_mode; a.gd_mode = gd_mode;
+    a.n_sets = n_sets; a.H = H; a.P = nn_param_count(H, L); a.max_steps = max_steps;
+    a.t = t; a.meal = meal; a.tvns = tvns; a.gd = gd; a.ode_p = ode_p; a.nn_p = nn_p;
+    a.nsteps = nsteps; a.status = status;
+    a.tape = (const R *)tape;
+    a.tape_seg = (const int32_t *)((const char *)tape + (size_t)B * max_steps * 8 * sizeof(R));
+    a.gy = gy; a.gx0 = gx0; a.gnn = gnn; a.gode = gode;
+    return launch_solve_bwd<R>((hipStream_t)stream, a, L, method);
+}
+
+template <typename R>
+int rhs_bwd(void *stream, int B, const R *x, const R *t, const R *meal, const R *tvns, const R *gd, const R *ode_p,
+            const R *nn_p, int H, int L, const R *gout, R *gx, R *gt, R *gnn, R *gode)
+{
+    if (B < 0 || !x || !ode_p || !nn_p || !gout || !gx) return HODE_EINVAL;
+    if (H < 1 || H > HODE_MAX_HIDDEN || L < 1 || L > HODE_MAX_LAYERS) return HODE_EUNSUPPORTED;
+    if (B == 0) return HODE_OK;
+    RhsArgs<R> a{};
+    a.B = B; a.H = H; a.P = nn_param_count(H, L);
+    a.x = x; a.t = t; a.meal = meal; a.tvns = tvns; a.gd = gd; a.ode_p = ode_p; a.nn_p = nn_p;
+    a.gout = gout; a.gx = gx; a.gt = gt; a.gnn = gnn; a.gode = gode;
+    return launch_rhs_bwd<R>((hipStream_t)stream, a, L);
+}
+
 }  // namespace
 
 extern "C" {
@@ -88,6 +126,52 @@ int hode_solve_fwd_f64(void *stream, int B, int T, const double *x0, const doubl
 {
     return solve_fwd<double>(stream, B, T, x0, t, t_batched, meal, meal_mode, tvns, tvns_mode, gd, gd_mode, ode_p, nn_p,
                              n_sets, H, L, method, rtol, atol, max_steps, y, status, nsteps, nfev, tape);
+}
+
+int hode_rhs_bwd_f32(void *stream, int B, const float *x, const float *t, const float *meal, const float *tvns,
+                     const float *gd, const float *ode_p, const float *nn_p, int H, int L, const float *gout, float *gx,
+                     float *gt, float *gnn, float *gode)
+{
+    return rhs_bwd<float>(stream, B, x, t, meal, tvns, gd, ode_p, nn_p, H, L, gout, gx, gt, gnn, gode);
+}
+int hode_rhs_bwd_f64(void *stream, int B, const double *x, const double *t, const double *meal, const double *tvns,
+                     const double *gd, const double *ode_p, const double *nn_p, int H, int L, const double *gout,
+                     double *gx, double *gt, double *gnn, double *gode)
+{
+    return rhs_bwd<double>(stream, B, x, t, meal, tvns, gd, ode_p, nn_p, H, L, gout, gx, gt, gnn, gode);
+}
+
+int hode_solve_bwd_f32(void *stream, int B, int T, const float *t, int t_batched, const float *meal, int meal_mode,
+                       const float *tvns, int tvns_mode, const float *gd, int gd_mode, const float *ode_p,
+                       const float *nn_p, int n_sets, int H, int L, int method, int max_steps, const int32_t *nsteps,
+                       const int32_t *status, const void *tape, const float *gy, float *gx0, float *gnn, float *gode)
+{
+    return solve_bwd<float>(stream, B, T, t, t_batched, meal, meal_mode, tvns, tvns_mode, gd, gd_mode, ode_p, nn_p,
+                            n_sets, H, L, method, max_steps, nsteps, status, tape, gy, gx0, gnn, gode);
+}
+int hode_solve_bwd_f64(void *stream, int B, int T, const double *t, int t_batched, const double *meal, int meal_mode,
+                       const double *tvns, int tvns_mode, const double *gd, int gd_mode, const double *ode_p,
+                       const double *nn_p, int n_sets, int H, int L, int method, int max_steps, const int32_t *nsteps,
+                       const int32_t *status, const void *tape, const double *gy, double *gx0, double *gnn, double *gode)
+{
+    return solve_bwd<double>(stream, B, T, t, t_batched, meal, meal_mode, tvns, tvns_mode, gd, gd_mode, ode_p, nn_p,
+                             n_sets, H, L, method, max_steps, nsteps, status, tape, gy, gx0, gnn, gode);
+}
+
+int hode_adam_step_f32(void *stream, int64_t n, float *p, const float *g, float *m, float *v, float lr, float beta1,
+                       float beta2, float eps, int step, float max_norm, float grad_scale, float weight_decay,
+                       void *scratch)
+{
+    if (n < 0 || !p || !g || !m || !v || !scratch || step < 1) return HODE_EINVAL;
+    return launch_adam((hipStream_t)stream, n, p, g, m, v, lr, beta1, beta2, eps, step, max_norm, grad_scale,
+                       weight_decay, scratch);
+}
+
+int hode_mse_fwd_bwd_f32(void *stream, int64_t n, const float *y, const float *obs, float scale, double *loss_sum,
+                         float *gy)
+{
+    if (n < 0 || !y || !obs || !loss_sum) return HODE_EINVAL;
+    return launch_mse((hipStream_t)stream, n, y, obs, scale, loss_sum, gy);
 }
 
 int hode_selftest_xlane(void *stream, int32_t *out)

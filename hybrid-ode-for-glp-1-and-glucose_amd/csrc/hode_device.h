@@ -15,6 +15,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "../../include/hode.h"
 
 namespace hode {
 
@@ -155,6 +156,70 @@ template <typename R> struct DP {
     static constexpr R e1 = R(-71) / 57600, e3 = R(71) / 16695, e4 = R(-71) / 1920, e5 = R(17253) / 339200, e6 = R(-22) / 525, e7 = R(1) / 40;
 };
 
+// sum over the 8 lanes that share (lane & 7), result on all of them
+template <typename R> __device__ __forceinline__ R group_sum8(R v)
+{
+    v += xlane_xor8(v);
+    v = allsum_x16(v);
+    return allsum_x32(v);
+}
+
+// ------------------------------------------------------------------------------------------
+// Runge-Kutta tableaux as data.  The stage derivatives of a step are PACKED into one VGPR:
+// lanes 8s..8s+7 hold stage s (component = lane & 7), so a stage combination
+//   Y_s = Y + h * sum_j a_sj K_j   is   Y + h * group_sum8(coef_s * KK)
+// with a per-lane coefficient row coef_s[lane] = a[s][lane >> 3] fetched from an LDS table.
+// One copy of the RHS code serves every stage (the stage loop is NOT unrolled).
+struct TableauData {
+    double A[8][8];   // A[s][j]; for DP5(4) row 6 = the 5th-order weights (FSAL stage)
+    double bw[8];     // solution weights
+    double c[8];      // nodes
+    double E[8];      // error-estimate weights (DP5(4) only)
+    int S;            // stages that carry the solution (backward sweeps these)
+};
+__constant__ TableauData kTableau[2] = {
+    // HODE_METHOD_DP54: Dormand-Prince 5(4) (scipy/integrate/_ivp/rk.py:377-401)
+    {{{0},
+      {1.0 / 5},
+      {3.0 / 40, 9.0 / 40},
+      {44.0 / 45, -56.0 / 15, 32.0 / 9},
+      {19372.0 / 6561, -25360.0 / 2187, 64448.0 / 6561, -212.0 / 729},
+      {9017.0 / 3168, -355.0 / 33, 46732.0 / 5247, 49.0 / 176, -5103.0 / 18656},
+      {35.0 / 384, 0, 500.0 / 1113, 125.0 / 192, -2187.0 / 6784, 11.0 / 84},
+      {0}},
+     {35.0 / 384, 0, 500.0 / 1113, 125.0 / 192, -2187.0 / 6784, 11.0 / 84, 0, 0},
+     {0, 1.0 / 5, 3.0 / 10, 4.0 / 5, 8.0 / 9, 1, 1, 0},
+     {-71.0 / 57600, 0, 71.0 / 16695, -71.0 / 1920, 17253.0 / 339200, -22.0 / 525, 1.0 / 40, 0},
+     6},
+    // HODE_METHOD_RK4: the classic 4-stage scheme
+    {{{0}, {0.5}, {0, 0.5}, {0, 0, 1.0}, {0}, {0}, {0}, {0}},
+     {1.0 / 6, 2.0 / 6, 2.0 / 6, 1.0 / 6, 0, 0, 0, 0},
+     {0, 0.5, 0.5, 1.0, 0, 0, 0, 0},
+     {0},
+     4}};
+
+// LDS coefficient rows (per workgroup): rowsA[s][lane] = A[s][lane>>3]; row 7 = E (DP) / bw (RK4)
+template <typename R> __device__ __forceinline__ void tableau_rows_store(R *rows, int method, int tid, int nthreads)
+{
+    for (int i = tid; i < 8 * kWave; i += nthreads) {
+        const int s = i >> 6, l = i & 63;
+        double v = kTableau[method].A[s][l >> 3];
+        if (s == 7) v = (method == HODE_METHOD_DP54) ? kTableau[method].E[l >> 3] : kTableau[method].bw[l >> 3];
+        rows[i] = (R)v;
+    }
+}
+// transposed rows for the adjoint: rowsT[s][lane] = A[lane>>3][s] (only stages < S); row 7 = 1 for stages < S
+template <typename R> __device__ __forceinline__ void tableau_rowsT_store(R *rows, int method, int tid, int nthreads)
+{
+    const int S = kTableau[method].S;
+    for (int i = tid; i < 8 * kWave; i += nthreads) {
+        const int s = i >> 6, l = i & 63, j = l >> 3;
+        double v = (j < S && s < S) ? kTableau[method].A[j][s] : 0.0;
+        if (s == 7) v = (j < S) ? 1.0 : 0.0;
+        rows[i] = (R)v;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // MLP parameters of ONE parameter set, register-resident.  NL = number of hidden layers (1..4).
 // Lane j owns hidden unit j of every layer.  H < 64 is zero-padded (relu(0) = 0 keeps it exact).
@@ -163,7 +228,7 @@ template <typename R, int NL> struct MlpRegs {
     R b[NL];                          // b_l[j]
     R wh[(NL > 1) ? NL - 1 : 1][kMaxH]; // W_l[j][0..63], l = 2..NL
     R w5[6];                          // Wout[o][j]
-    R b5;                             // lane o < 6: bout[o]
+    R b5;                             // lane l: bout[l & 7] (0 for slots 6,7)
 };
 
 __host__ __device__ inline int nn_param_count(int H, int L) { return 9 * H + H + (L - 1) * (H * H + H) + 6 * H + 6; }
@@ -209,7 +274,7 @@ __device__ __forceinline__ void mlp_load(MlpRegs<R, NL> &W, const R *__restrict_
 #pragma unroll
     for (int o = 0; o < 6; ++o) W.w5[o] = live * p[o * H + j];
     p += 6 * H;
-    W.b5 = (lane < 6) ? p[(lane < 6) ? lane : 0] : R(0);
+    W.b5 = ((lane & 7) < 6) ? p[((lane & 7) < 6) ? (lane & 7) : 0] : R(0);   // replicated per 8-lane group
 }
 
 // ------------------------------------------------------------------------------------------
@@ -246,8 +311,9 @@ template <typename R, int NL> struct MlpActs { R h[NL]; };
 
 // ------------------------------------------------------------------------------------------
 // RHS  f(t, x, u) = ODECore + NNResidual  (models/hybrid_ode_nn.py:108-134)
-//   Y   lane-distributed state (lane i < 6 holds x_i)
-//   returns lane-distributed derivative (lanes >= 6 hold 0)
+//   Y   lane-distributed state: lane l holds x_{l&7} (replicated over the eight 8-lane groups;
+//       only lanes 0..5 are read)
+//   returns the derivative in the same replicated layout (component slots 6,7 hold 0)
 template <typename R, int NL, bool KEEP>
 __device__ __forceinline__ R rhs_eval(const MlpRegs<R, NL> &W, const OdeP<R> &o, R t, R Y, R meal, R tvns,
                                       R gde /* Hill term, 0 without GD */, int lane, MlpActs<R, NL> *acts)
@@ -262,7 +328,8 @@ __device__ __forceinline__ R rhs_eval(const MlpRegs<R, NL> &W, const OdeP<R> &o,
     const R k_GE = o.k_GE0 * (R(1) - gde);
     const R dFFA = -o.p_7 * FFA - o.p_8 * I * FFA + o.p_9 * G * FFA;
     const R dG = meal - R(0.01) * (I - o.I_b) + R(0.005) * (Glu - o.Glu_b) - k_GE * G;
-    R mech = (lane == 0) ? dG : (lane == 1) ? dI : (lane == 2) ? dGlu : (lane == 3) ? dGLP1 : (lane == 5) ? dFFA : R(0);
+    const int c8 = lane & 7;
+    R mech = (c8 == 0) ? dG : (c8 == 1) ? dI : (c8 == 2) ? dGlu : (c8 == 3) ? dGLP1 : (c8 == 5) ? dFFA : R(0);
     // ---- MLP (models/nn_residual.py:138-147): input row [t, G, I, Glu, GLP1, GE, FFA, glp1:=GLP1, tvns]
     R h = W.b[0];
     h = rfma(W.w1[0], t, h);
@@ -291,7 +358,184 @@ __device__ __forceinline__ R rhs_eval(const MlpRegs<R, NL> &W, const OdeP<R> &o,
 #pragma unroll
     for (int q = 0; q < 6; ++q) p[q] = W.w5[q] * h;
     const R nn = wave_reduce6_to_lanes(p, lane);
-    return (lane < 6) ? (mech + nn + W.b5) : R(0);
+    return (c8 < 6) ? (mech + nn + W.b5) : R(0);
+}
+
+// ------------------------------------------------------------------------------------------
+// Backward (VJP) building blocks -- used by K4 (adjoint) and K5 (RHS backward).
+//
+// Register-resident gradient accumulators mirror MlpRegs: lane j owns the gradient of row j.
+template <typename R, int NL> struct MlpGrads {
+    R w1[9];
+    R b[NL];
+    R wh[(NL > 1) ? NL - 1 : 1][kMaxH];
+    R w5[6];
+    R b5;   // lane o < 6: d bout[o]
+};
+template <typename R, int NL> __device__ __forceinline__ void grads_zero(MlpGrads<R, NL> &g)
+{
+#pragma unroll
+    for (int i = 0; i < 9; ++i) g.w1[i] = R(0);
+#pragma unroll
+    for (int l = 0; l < NL; ++l) g.b[l] = R(0);
+#pragma unroll
+    for (int l = 0; l < NL - 1; ++l)
+#pragma unroll
+        for (int k = 0; k < kMaxH; ++k) g.wh[l][k] = R(0);
+#pragma unroll
+    for (int o = 0; o < 6; ++o) g.w5[o] = R(0);
+    g.b5 = R(0);
+}
+
+__device__ __forceinline__ void atomic_add(float *p, float v) { unsafeAtomicAdd(p, v); }
+__device__ __forceinline__ void atomic_add(double *p, double v) { unsafeAtomicAdd(p, v); }
+
+// flush the per-lane accumulators into the flat gradient vector (PyTorch parameters() order)
+template <typename R, int NL>
+__device__ __forceinline__ void grads_flush(const MlpGrads<R, NL> &g, R *__restrict__ gp, int H, int lane)
+{
+    const bool live = lane < H;
+    if (live) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) atomic_add(gp + lane * 9 + i, g.w1[i]);
+    }
+    gp += 9 * H;
+    if (live) atomic_add(gp + lane, g.b[0]);
+    gp += H;
+#pragma unroll
+    for (int l = 0; l < NL - 1; ++l) {
+        if (live) {
+#pragma unroll
+            for (int k = 0; k < kMaxH; ++k)
+                if (k < H) atomic_add(gp + (size_t)lane * H + k, g.wh[l][k]);
+        }
+        gp += (size_t)H * H;
+        if (live) atomic_add(gp + lane, g.b[l + 1]);
+        gp += H;
+    }
+    if (live) {
+#pragma unroll
+        for (int o = 0; o < 6; ++o) atomic_add(gp + o * H + lane, g.w5[o]);
+    }
+    gp += 6 * H;
+    if (lane < 6) atomic_add(gp + lane, g.b5);
+}
+
+// LDS image of the TRANSPOSED hidden matrices: element W_l[j][k] at ((j/4)*64 + k)*4 + (j%4), so
+// lane k fetches W_l[4jj..4jj+3][k] with one conflict-free 16/32-byte read.
+template <typename R, int NL>
+__device__ __forceinline__ void wt_store(R *__restrict__ wt, const MlpRegs<R, NL> &W, int lane)
+{
+#pragma unroll
+    for (int l = 0; l < NL - 1; ++l)
+#pragma unroll
+        for (int k = 0; k < kMaxH; ++k)
+            wt[(size_t)l * kMaxH * kMaxH + ((lane >> 2) * kMaxH + k) * 4 + (lane & 3)] = W.wh[l][k];
+}
+
+template <typename R> struct alignas(sizeof(R) * 4) Vec4 { R v[4]; };
+
+// VJP of rhs_eval.  kb = lane-distributed cotangent of f; returns the lane-distributed cotangent
+// of the state, accumulates parameter gradients.  acts = activations saved by rhs_eval<KEEP>.
+//   go[17] (GODE): wave-uniform accumulators of d/d(ode constants)
+template <typename R, int NL, bool GODE, bool GT>
+__device__ __forceinline__ R rhs_vjp(const MlpRegs<R, NL> &W, const R *__restrict__ wt, const OdeP<R> &o, R t, R Y,
+                                     R meal, R tvns, R gde, R gd_in, bool use_gd, int lane,
+                                     const MlpActs<R, NL> &acts, R kb, MlpGrads<R, NL> &g, R (&go)[17], R *gt_out)
+{
+    (void)meal;
+    const R G = lane_bcast(Y, 0), I = lane_bcast(Y, 1), Glu = lane_bcast(Y, 2), GLP1 = lane_bcast(Y, 3),
+            GE = lane_bcast(Y, 4), FFA = lane_bcast(Y, 5);
+    const R lG = lane_bcast(kb, 0), lI = lane_bcast(kb, 1), lGlu = lane_bcast(kb, 2), lGLP = lane_bcast(kb, 3),
+            lGE = lane_bcast(kb, 4), lF = lane_bcast(kb, 5);
+    // ---- mechanistic J^T kb (analytic Jacobian of models/ode_core.py:124-153)
+    const R Pi = R(1) + o.rho * GLP1;
+    const R den1 = o.EC_50 + GLP1, den2 = o.K_m + G;
+    const R k_GE = o.k_GE0 * (R(1) - gde);
+    const R r1 = R(1) / den1, r2 = R(1) / den2;
+    const R oG = -k_GE * lG + Pi * o.a_GI * lI + o.V_max * o.K_m * r2 * r2 * lGLP + o.p_9 * FFA * lF;
+    const R oI = R(-0.01) * lG - o.k_I * lI - o.p_8 * FFA * lF;
+    const R oGlu = R(0.005) * lG - o.E_max * GLP1 * r1 * lGlu;
+    const R oGLP = o.rho * o.a_GI * (G - o.G_b) * lI - o.E_max * o.EC_50 * r1 * r1 * (Glu - o.Glu_b) * lGlu - o.k_L * lGLP;
+    const R oF = (-o.p_7 - o.p_8 * I + o.p_9 * G) * lF;
+    const int c8 = lane & 7;
+    const R mech = (c8 == 0) ? oG : (c8 == 1) ? oI : (c8 == 2) ? oGlu : (c8 == 3) ? oGLP : (c8 == 5) ? oF : R(0);
+    if constexpr (GODE) {
+        go[0] += lI * Pi * (G - o.G_b);
+        go[1] -= lI * (I - o.I_b);
+        go[2] += lI * GLP1 * o.a_GI * (G - o.G_b);
+        go[3] -= lI * Pi * o.a_GI;
+        go[4] += lI * o.k_I + lG * R(0.01);
+        go[5] -= lGlu * GLP1 * r1 * (Glu - o.Glu_b);
+        go[6] += lGlu * o.E_max * GLP1 * r1 * r1 * (Glu - o.Glu_b);
+        go[7] += lGlu * o.E_max * GLP1 * r1 - lG * R(0.005);
+        go[8] += lGLP * G * r2;
+        go[9] -= lGLP * o.V_max * G * r2 * r2;
+        go[10] -= lGLP * GLP1;
+        go[11] -= lG * G * (R(1) - gde);
+        if (use_gd && gd_in > R(0)) {
+            const R u = rpow(gd_in, o.g), v = rpow(o.IGD_50, o.g), s2 = (v + u) * (v + u);
+            go[12] += lG * o.k_GE0 * G * (-u * o.g * rpow(o.IGD_50, o.g - R(1)) / s2);
+            go[13] += lG * o.k_GE0 * G * (u * v * (rlog(gd_in) - rlog(o.IGD_50)) / s2);
+        }
+        go[14] -= lF * FFA;
+        go[15] -= lF * I * FFA;
+        go[16] += lF * G * FFA;
+    }
+    // ---- MLP backward
+    const R hl = acts.h[NL - 1];
+    g.b5 += kb;                                  // lane o < 6 holds d bout[o] (other groups hold copies)
+    g.w5[0] = rfma(lG, hl, g.w5[0]);
+    g.w5[1] = rfma(lI, hl, g.w5[1]);
+    g.w5[2] = rfma(lGlu, hl, g.w5[2]);
+    g.w5[3] = rfma(lGLP, hl, g.w5[3]);
+    g.w5[4] = rfma(lGE, hl, g.w5[4]);
+    g.w5[5] = rfma(lF, hl, g.w5[5]);
+    R d = W.w5[0] * lG;
+    d = rfma(W.w5[1], lI, d);
+    d = rfma(W.w5[2], lGlu, d);
+    d = rfma(W.w5[3], lGLP, d);
+    d = rfma(W.w5[4], lGE, d);
+    d = rfma(W.w5[5], lF, d);
+    d = (hl > R(0)) ? d : R(0);
+#pragma unroll
+    for (int l = NL - 1; l >= 1; --l) {           // hidden matrix l-1 maps acts.h[l-1] -> acts.h[l]
+        const R hin = acts.h[l - 1];
+        g.b[l] += d;
+#pragma unroll
+        for (int k = 0; k < kMaxH; ++k) g.wh[l - 1][k] = rfma(d, lane_bcast(hin, k), g.wh[l - 1][k]);
+        const Vec4<R> *wt4 = reinterpret_cast<const Vec4<R> *>(wt + (size_t)(l - 1) * kMaxH * kMaxH);
+        R acc0 = R(0), acc1 = R(0);
+#pragma unroll 2
+        for (int jj = 0; jj < kMaxH / 4; ++jj) {          // partial unroll keeps only two 16-byte reads in flight
+            const Vec4<R> w = wt4[jj * kMaxH + lane];
+            acc0 = rfma(w.v[0], lane_bcast(d, 4 * jj + 0), acc0);
+            acc1 = rfma(w.v[1], lane_bcast(d, 4 * jj + 1), acc1);
+            acc0 = rfma(w.v[2], lane_bcast(d, 4 * jj + 2), acc0);
+            acc1 = rfma(w.v[3], lane_bcast(d, 4 * jj + 3), acc1);
+        }
+        d = (hin > R(0)) ? (acc0 + acc1) : R(0);
+    }
+    g.b[0] += d;
+    g.w1[0] = rfma(d, t, g.w1[0]);
+    g.w1[1] = rfma(d, G, g.w1[1]);
+    g.w1[2] = rfma(d, I, g.w1[2]);
+    g.w1[3] = rfma(d, Glu, g.w1[3]);
+    g.w1[4] = rfma(d, GLP1, g.w1[4]);
+    g.w1[5] = rfma(d, GE, g.w1[5]);
+    g.w1[6] = rfma(d, FFA, g.w1[6]);
+    g.w1[7] = rfma(d, GLP1, g.w1[7]);
+    g.w1[8] = rfma(d, tvns, g.w1[8]);
+    R p[6];
+    p[0] = W.w1[1] * d;
+    p[1] = W.w1[2] * d;
+    p[2] = W.w1[3] * d;
+    p[3] = (W.w1[4] + W.w1[7]) * d;               // GLP1 feeds inputs 4 and 7
+    p[4] = W.w1[5] * d;
+    p[5] = W.w1[6] * d;
+    const R nn = wave_reduce6_to_lanes(p, lane);
+    if constexpr (GT) *gt_out = wave_allsum(W.w1[0] * d);
+    return (c8 < 6) ? (mech + nn) : R(0);
 }
 
 }  // namespace hode

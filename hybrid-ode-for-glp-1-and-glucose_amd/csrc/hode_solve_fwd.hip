@@ -24,28 +24,34 @@ template <> struct Eps<double> { static constexpr double v = 2.220446049250313e-
 template <typename R, int NL, int METHOD, int LB>
 __global__ __launch_bounds__(64, LB) void solve_fwd_kernel(const SolveArgs<R> a)
 {
+    __shared__ R rows[8 * kWave];             // tableau coefficient rows (hode_device.h)
     const int lane = threadIdx.x;
+    const int c8 = lane & 7, grp = lane >> 3;
     const int b = blockIdx.x;                 // one wave == one trajectory
     const int T = a.T;
     const int set = b / (a.B / a.n_sets);
 
+    tableau_rows_store<R>(rows, METHOD, lane, 64);
     MlpRegs<R, NL> W;
     mlp_load<R, NL>(W, a.nn_p + (size_t)set * a.P, a.H, lane);
     OdeP<R> o;
     ode_load(o, a.ode_p + 17 * set);
+    __syncthreads();
 
     const R *__restrict__ tg = a.t + (a.t_batched ? (size_t)b * T : 0);
     R *__restrict__ yb = a.y + (size_t)b * T * 6;
     R *__restrict__ tape = a.tape ? a.tape + (size_t)b * a.max_steps * 8 : nullptr;
     int *__restrict__ tseg = a.tape ? a.tape_seg + (size_t)b * a.max_steps : nullptr;
     const bool use_gd = a.gd_mode != 0;
+    const TableauData &tab = kTableau[METHOD];
 
-    R Y = (lane < 6) ? a.x0[(size_t)b * 6 + lane] : R(0);
+    // state, replicated over the eight 8-lane groups: lane l holds y_{l&7}
+    R Y = (c8 < 6) ? a.x0[(size_t)b * 6 + c8] : R(0);
     if (lane < 6) yb[lane] = Y;
 
     int st = HODE_ST_OK, ns = 0, nf = 0, k = 0;
     R h_abs = R(0);
-    R K1 = R(0);
+    R KK = R(0);                              // packed stage derivatives: lanes 8s..8s+7 = K_{s+1}
     bool have_f = false;
 
     for (; k + 1 < T && st == HODE_ST_OK; ++k) {
@@ -66,27 +72,34 @@ __global__ __launch_bounds__(64, LB) void solve_fwd_kernel(const SolveArgs<R> a)
             const R gde = use_gd ? gd_effect(o, rfma(al, dd, d0)) : R(0);
             return rhs_eval<R, NL, false>(W, o, ts, Ys, rfma(al, dm, m0), rfma(al, dv, v0), gde, lane, nullptr);
         };
+        auto tape_put = [&](R tc, R h) {
+            if (tape) {
+                // entry = {t, h, y0..y5}: lanes 0..5 store the state, lanes 6,7 store t and h
+                const R e = (lane < 6) ? Y : (lane == 6) ? tc : h;
+                if (lane < 8) tape[(size_t)ns * 8 + ((lane < 6) ? lane + 2 : lane - 6)] = e;
+                if (lane == 0) tseg[ns] = k;
+            }
+        };
         R tc = t0;
 
         if constexpr (METHOD == HODE_METHOD_RK4) {
-            const R hh = len, th = t0 + R(0.5) * hh;
-            const R k1 = f_at(t0, Y);
-            const R k2 = f_at(th, rfma(R(0.5) * hh, k1, Y));
-            const R k3 = f_at(th, rfma(R(0.5) * hh, k2, Y));
-            const R k4 = f_at(t1, rfma(hh, k3, Y));
-            if (tape && ns < a.max_steps) {
-                const R e = (lane == 0) ? t0 : (lane == 1) ? hh : dpp_mov<0x112, 0xF, true>(R(0), Y);   // row_shr:2
-                if (lane < 8) tape[(size_t)ns * 8 + lane] = e;
-                if (lane == 0) tseg[ns] = k;
+            const R hh = len;
+            KK = R(0);
+#pragma unroll 1
+            for (int s = 0; s < 4; ++s) {
+                const R Ys = rfma(hh, group_sum8(rows[s * kWave + lane] * KK), Y);
+                const R F = f_at(rfma((R)tab.c[s], hh, t0), Ys);
+                KK = (grp == s) ? F : KK;
             }
-            Y = rfma(hh / R(6), (k1 + R(2) * k2) + (R(2) * k3 + k4), Y);
+            if (ns < a.max_steps) tape_put(t0, hh);
+            Y = rfma(hh, group_sum8(rows[7 * kWave + lane] * KK), Y);
             nf += 4;
             ns += 1;
         } else {
             if (!have_f) {
                 // first derivative + Hairer's initial step (scipy/integrate/_ivp/common.py:68-135)
-                K1 = f_at(t0, Y);
-                const R sc = (lane < 6) ? (a.atol + rabs(Y) * a.rtol) : R(1);
+                const R K1 = f_at(t0, Y);
+                const R sc = (c8 < 6) ? (a.atol + rabs(Y) * a.rtol) : R(1);
                 const R q0 = Y / sc, q1 = K1 / sc;
                 const float dn0 = sqrtf((float)first_lane(oct_allsum(q0 * q0)) / 6.0f);
                 const float dn1 = sqrtf((float)first_lane(oct_allsum(q1 * q1)) / 6.0f);
@@ -98,6 +111,7 @@ __global__ __launch_bounds__(64, LB) void solve_fwd_kernel(const SolveArgs<R> a)
                 const float h1 = (dn1 <= 1e-15f && dn2 <= 1e-15f) ? fmaxf(1e-6f, h0 * 1e-3f)
                                                                    : powf(0.01f / fmaxf(dn1, dn2), 0.2f);
                 h_abs = first_lane((R)fminf(fminf(100.0f * h0, h1), (float)len));
+                KK = (grp == 0) ? K1 : R(0);
                 nf += 2;
                 have_f = true;
             }
@@ -112,33 +126,31 @@ __global__ __launch_bounds__(64, LB) void solve_fwd_kernel(const SolveArgs<R> a)
                     if (tn >= t1 || (t1 - tn) < R(0.01) * h) { tn = t1; h = tn - tc; clipped = true; }
                     h = first_lane(h);
                     tn = first_lane(tn);
-                    using D = DP<R>;
-                    const R K2 = f_at(rfma(D::c2, h, tc), rfma(h * D::a21, K1, Y));
-                    const R K3 = f_at(rfma(D::c3, h, tc), rfma(h, D::a31 * K1 + D::a32 * K2, Y));
-                    const R K4 = f_at(rfma(D::c4, h, tc), rfma(h, D::a41 * K1 + D::a42 * K2 + D::a43 * K3, Y));
-                    const R K5 = f_at(rfma(D::c5, h, tc), rfma(h, D::a51 * K1 + D::a52 * K2 + D::a53 * K3 + D::a54 * K4, Y));
-                    const R K6 = f_at(tn, rfma(h, D::a61 * K1 + D::a62 * K2 + D::a63 * K3 + D::a64 * K4 + D::a65 * K5, Y));
-                    const R Yn = rfma(h, D::b1 * K1 + D::b3 * K3 + D::b4 * K4 + D::b5 * K5 + D::b6 * K6, Y);
-                    const R K7 = f_at(tn, Yn);
+                    KK = (grp == 0) ? KK : R(0);          // drop stale stages (0 * NaN would poison the sums)
+                    R Ys = Y, F = R(0);
+#pragma unroll 1
+                    for (int s = 1; s <= 6; ++s) {        // stages 2..6 and the FSAL stage (row 6 = 5th-order weights)
+                        Ys = rfma(h, group_sum8(rows[s * kWave + lane] * KK), Y);
+                        const R ts = (s >= 5) ? tn : rfma((R)tab.c[s], h, tc);
+                        F = f_at(ts, Ys);
+                        KK = (grp == s) ? F : KK;
+                    }
+                    const R Yn = Ys;                      // 5th-order solution
                     nf += 6;
-                    const R err = h * (D::e1 * K1 + D::e3 * K3 + D::e4 * K4 + D::e5 * K5 + D::e6 * K6 + D::e7 * K7);
+                    const R err = h * group_sum8(rows[7 * kWave + lane] * KK);
                     const R ymax = rabs(Y) > rabs(Yn) ? rabs(Y) : rabs(Yn);
-                    const R qe = (lane < 6) ? err / (a.atol + ymax * a.rtol) : R(0);
+                    const R qe = (c8 < 6) ? err / (a.atol + ymax * a.rtol) : R(0);
                     float en = sqrtf((float)first_lane(oct_allsum(qe * qe)) / 6.0f);
-                    const float ysum = (float)first_lane(oct_allsum((lane < 6) ? Yn : R(0)));
+                    const float ysum = (float)first_lane(oct_allsum(Yn));
                     if (!(en == en) || !(fabsf(ysum) <= 3.0e38f) || !(fabsf(en) <= 3.0e38f)) en = 1e30f;
                     if (en < 1.0f) {
                         float fac = (en == 0.0f) ? 10.0f : fminf(10.0f, 0.9f * __builtin_exp2f(-0.2f * __builtin_log2f(en)));
                         if (rejected) fac = fminf(1.0f, fac);
-                        if (tape) {
-                            const R e = (lane == 0) ? tc : (lane == 1) ? h : dpp_mov<0x112, 0xF, true>(R(0), Y);   // row_shr:2
-                            if (lane < 8) tape[(size_t)ns * 8 + lane] = e;
-                            if (lane == 0) tseg[ns] = k;
-                        }
+                        tape_put(tc, h);
                         const R hn = h * (R)fac;
                         h_abs = first_lane((clipped && hn < h_abs) ? h_abs : hn);   // a clipped step never shrinks the proposal
                         Y = Yn;
-                        K1 = K7;                                       // FSAL
+                        KK = (grp == 0) ? F : KK;         // FSAL: K7 becomes K1
                         tc = tn;
                         ns++;
                         break;
@@ -151,7 +163,7 @@ __global__ __launch_bounds__(64, LB) void solve_fwd_kernel(const SolveArgs<R> a)
             }
         }
         if (st == HODE_ST_OK) {
-            const float ysum = (float)first_lane(oct_allsum((lane < 6) ? Y : R(0)));
+            const float ysum = (float)first_lane(oct_allsum(Y));
             if (!(fabsf(ysum) <= 3.0e38f)) st = HODE_ST_NONFINITE;
             else if (lane < 6) yb[(size_t)(k + 1) * 6 + lane] = Y;
         }

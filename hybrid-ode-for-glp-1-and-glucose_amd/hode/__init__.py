@@ -5,5 +5,5 @@ path (RHS, DP5(4) stepping, adjoint, Adam) runs in the hand-written HIP kernels;
 CPU / eager fallback -- if the library or a GPU is missing the calls raise.
 """
 from . import _capi as capi  # noqa: F401
-from ._capi import (METHOD_DP54, METHOD_RK4, HodeError, lib_path, load, n_params, solve_fwd, rhs_fwd,  # noqa: F401
-                    selftest_xlane, version)
+from ._capi import (METHOD_DP54, METHOD_RK4, HodeError, adam_step, lib_path, load, mse_fwd_bwd, n_params,  # noqa: F401
+                    rhs_bwd, rhs_fwd, selftest_xlane, solve_bwd, solve_fwd, version)

@@ -158,3 +158,75 @@ def solve_fwd(x0, t, meal, tvns, gd, ode_p, nn_p, H, L, method=METHOD_DP54, rtol
     _check(rc, "hode_solve_fwd")
     s.ctx = (t, t_batched, meal, tvns, gd, ode_p, nn_p, n_sets, H, L, method)
     return s
+
+
+def solve_bwd(sol, gy, want_gnn=True, want_gode=False):
+    """Reverse-time discrete adjoint over the tape of `sol` (made with want_tape=True).
+    Returns (gx0[B,6], gnn[n_sets*P] or None, gode[n_sets*17] or None)."""
+    if sol.tape is None:
+        raise HodeError("solve_bwd needs a solution computed with want_tape=True")
+    t, t_batched, meal, tvns, gd, ode_p, nn_p, n_sets, H, L, method = sol.ctx
+    dt, dev = sol.y.dtype, sol.y.device
+    B, T = sol.y.shape[:2]
+    gy = gy.to(device=dev, dtype=dt).contiguous()
+    if tuple(gy.shape) != (B, T, 6):
+        raise HodeError("gy must be [B,T,6]")
+    gx0 = torch.empty(B, 6, dtype=dt, device=dev)
+    gnn = torch.zeros(nn_p.numel(), dtype=dt, device=dev) if want_gnn else None
+    gode = torch.zeros(17 * n_sets, dtype=dt, device=dev) if want_gode else None
+    fn = getattr(load(), f"hode_solve_bwd_{_sfx(dt)}")
+    rc = fn(_stream(), C.c_int(B), C.c_int(T), _ptr(t), C.c_int(t_batched),
+            _ptr(meal), C.c_int(_mode(meal, B, T)), _ptr(tvns), C.c_int(_mode(tvns, B, T)),
+            _ptr(gd), C.c_int(_mode(gd, B, T)), _ptr(ode_p), _ptr(nn_p), C.c_int(n_sets), C.c_int(H), C.c_int(L),
+            C.c_int(method), C.c_int(sol.max_steps), _ptr(sol.nsteps), _ptr(sol.status), _ptr(sol.tape), _ptr(gy),
+            _ptr(gx0), _ptr(gnn), _ptr(gode))
+    _check(rc, "hode_solve_bwd")
+    return gx0, gnn, gode
+
+
+def rhs_bwd(x, t, meal, tvns, gd, ode_p, nn_p, H, L, gout, want_gt=False, want_gnn=True, want_gode=False):
+    _need_gpu(x)
+    dt, dev = x.dtype, x.device
+    x = x.contiguous()
+    B = x.shape[0]
+    t, meal, tvns, gd, gout = (_prep(v, dt, dev) for v in (t, meal, tvns, gd, gout))
+    ode_p, nn_p = _prep(ode_p, dt, dev), _prep(nn_p, dt, dev)
+    gx = torch.empty(B, 6, dtype=dt, device=dev)
+    gt = torch.empty(B, dtype=dt, device=dev) if want_gt else None
+    gnn = torch.zeros(nn_p.numel(), dtype=dt, device=dev) if want_gnn else None
+    gode = torch.zeros(17, dtype=dt, device=dev) if want_gode else None
+    fn = getattr(load(), f"hode_rhs_bwd_{_sfx(dt)}")
+    _check(fn(_stream(), C.c_int(B), _ptr(x), _ptr(t), _ptr(meal), _ptr(tvns), _ptr(gd), _ptr(ode_p), _ptr(nn_p),
+              C.c_int(H), C.c_int(L), _ptr(gout), _ptr(gx), _ptr(gt), _ptr(gnn), _ptr(gode)), "hode_rhs_bwd")
+    return gx, gt, gnn, gode
+
+
+def adam_step(p, g, m, v, lr, beta1=0.9, beta2=0.999, eps=1e-8, step=1, max_norm=0.0, grad_scale=1.0,
+              weight_decay=0.0, scratch=None):
+    """In-place fused clip + Adam on flat fp32 vectors (train/train_hybrid.py:255-261)."""
+    for a in (p, g, m, v):
+        _need_gpu(a)
+        if a.dtype != torch.float32 or not a.is_contiguous():
+            raise HodeError("adam_step needs contiguous fp32 tensors")
+    if scratch is None:
+        scratch = torch.empty(2, dtype=torch.float32, device=p.device)
+    _check(load().hode_adam_step_f32(_stream(), C.c_int64(p.numel()), _ptr(p), _ptr(g), _ptr(m), _ptr(v),
+                                     C.c_float(lr), C.c_float(beta1), C.c_float(beta2), C.c_float(eps), C.c_int(step),
+                                     C.c_float(max_norm), C.c_float(grad_scale), C.c_float(weight_decay),
+                                     _ptr(scratch)), "hode_adam_step")
+    return scratch
+
+
+def mse_fwd_bwd(y, obs, scale, loss_sum=None, want_grad=True):
+    """sum((y-obs)^2) accumulated into loss_sum (fp64[1]) and gy = 2*scale*(y-obs) in one pass."""
+    _need_gpu(y)
+    y = y.contiguous()
+    obs = obs.to(device=y.device, dtype=torch.float32).contiguous()
+    if y.dtype != torch.float32 or y.shape != obs.shape:
+        raise HodeError("mse_fwd_bwd needs fp32 tensors of equal shape")
+    if loss_sum is None:
+        loss_sum = torch.zeros(1, dtype=torch.float64, device=y.device)
+    gy = torch.empty_like(y) if want_grad else None
+    _check(load().hode_mse_fwd_bwd_f32(_stream(), C.c_int64(y.numel()), _ptr(y), _ptr(obs), C.c_float(scale),
+                                       _ptr(loss_sum), _ptr(gy)), "hode_mse_fwd_bwd")
+    return loss_sum, gy

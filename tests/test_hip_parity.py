@@ -168,3 +168,170 @@ def test_solve_fwd_parameter_sets(hode, golden_dir, g0):
                        dev(ode2[17:], dt), dev(nn2[13510:], dt), 64, 4)
     assert torch.equal(s.y[8:], a.y)
     assert not torch.equal(s.y[:8], a.y)
+
+
+# ============================================================================== backward
+def relnorm(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-300))
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.float64, 1e-11)])
+def test_rhs_bwd_vs_reference_autograd(hode, golden_dir, g0, dtype, tol):
+    """K5 vs torch autograd over the reference's ode_residual (G3 VJP vectors) and vs the oracle."""
+    r = np.load(os.path.join(golden_dir, "g123_rhs.npz"))
+    gx, gt, gnn, gode = hode.rhs_bwd(dev(r["x"], dtype), dev(r["t"], dtype), dev(r["meal"], dtype),
+                                     dev(r["tvns"], dtype), None, dev(g0["ode"], dtype), dev(g0["nn"], dtype), 64, 4,
+                                     dev(r["vjp_w"], dtype), want_gt=True, want_gode=True)
+    ox, onn, oode = O.rhs_vjp(r["x"], r["t"], r["meal"], r["tvns"], None, g0["ode"], g0["nn"], 64, 4, r["vjp_w"],
+                              np.float64)
+    assert relnorm(gx.cpu().numpy(), ox) < tol
+    assert relnorm(gnn.cpu().numpy(), onn) < tol
+    assert relnorm(gode.cpu().numpy(), oode) < tol
+    # the reference's own autograd (fp32 golden)
+    assert relnorm(gx.cpu().numpy(), r["vjp_gx"]) < 2e-6 + tol
+    assert relnorm(gnn.cpu().numpy(), r["vjp_gnn"]) < 2e-6 + tol
+    # d/dt: finite difference of the oracle
+    e = 1e-6
+    fp = O.rhs(r["x"], r["t"] + e, r["meal"], r["tvns"], None, g0["ode"], g0["nn"], 64, 4, np.float64)
+    fm = O.rhs(r["x"], r["t"] - e, r["meal"], r["tvns"], None, g0["ode"], g0["nn"], 64, 4, np.float64)
+    fd = ((fp - fm) * r["vjp_w"]).sum(1) / (2 * e)
+    assert np.max(np.abs(gt.cpu().numpy() - fd)) < 1e-4 * max(1.0, np.abs(fd).max())
+
+
+def test_rhs_bwd_with_gd_and_small_net(hode, golden_dir, g0, g0_small):
+    r = np.load(os.path.join(golden_dir, "g123_rhs.npz"))
+    dt = torch.float64
+    gd = r["gd"] + 10.0
+    gx, _, gnn, gode = hode.rhs_bwd(dev(r["x"], dt), dev(r["t"], dt), dev(r["meal"], dt), dev(r["tvns"], dt),
+                                    dev(gd, dt), dev(g0["ode"], dt), dev(g0["nn"], dt), 64, 4, dev(r["vjp_w"], dt),
+                                    want_gode=True)
+    ox, onn, oode = O.rhs_vjp(r["x"], r["t"], r["meal"], r["tvns"], gd, g0["ode"], g0["nn"], 64, 4, r["vjp_w"],
+                              np.float64)
+    assert relnorm(gx.cpu().numpy(), ox) < 1e-11 and relnorm(gnn.cpu().numpy(), onn) < 1e-11
+    assert relnorm(gode.cpu().numpy(), oode) < 1e-9
+    gx, _, gnn, _ = hode.rhs_bwd(dev(r["x"], dt), dev(r["t"], dt), dev(r["meal"], dt), dev(r["tvns"], dt), None,
+                                 dev(g0_small["ode"], dt), dev(g0_small["nn"], dt), 32, 2, dev(r["vjp_w"], dt))
+    ox, onn, _ = O.rhs_vjp(r["x"], r["t"], r["meal"], r["tvns"], None, g0_small["ode"], g0_small["nn"], 32, 2,
+                           r["vjp_w"], np.float64)
+    assert relnorm(gx.cpu().numpy(), ox) < 1e-11 and relnorm(gnn.cpu().numpy(), onn) < 1e-11
+
+
+def _adjoint_case(golden_dir, name, B=None):
+    g = np.load(os.path.join(golden_dir, f"g4_{name}.npz"))
+    rng = np.random.default_rng(5)
+    x0 = g["x0"] if B is None else g["x0"][:B]
+    meal = g["meal"] if B is None else g["meal"][:B]
+    tv = g["tvns"] if B is None else g["tvns"][:B]
+    c = rng.standard_normal((x0.shape[0], g["t"].shape[-1], 6))
+    return x0, g["t"], meal, tv, c
+
+
+@pytest.mark.parametrize("name,method", [("t61_rand", 0), ("t61_pulses", 0), ("t61_const", 0), ("t61_rand", 1)])
+def test_adjoint_fp64_vs_oracle(hode, golden_dir, g0, name, method):
+    """K4 in fp64 vs the oracle's discrete adjoint (itself checked against finite differences of
+    the oracle forward and of the REFERENCE forward, tests/test_oracle_golden.py).  Bar 1e-4
+    (BASELINE), held to 1e-8."""
+    x0, t, meal, tv, c = _adjoint_case(golden_dir, name)
+    dt = torch.float64
+    ref = O.solve(x0, t, meal, tv, None, g0["ode"], g0["nn"], 64, 4, method=method, rtol=1e-8, atol=1e-10,
+                  dtype=np.float64, want_tape=True)
+    rx, rnn, rode = O.solve_bwd(ref, c)
+    s = hode.solve_fwd(dev(x0, dt), dev(t, dt), dev(meal, dt), dev(tv, dt), None, dev(g0["ode"], dt),
+                       dev(g0["nn"], dt), 64, 4, method=method, rtol=1e-8, atol=1e-10, want_tape=True)
+    gx0, gnn, gode = hode.solve_bwd(s, dev(c, dt), want_gode=True)
+    assert np.array_equal(s.nsteps.cpu().numpy(), ref.nsteps)
+    assert relnorm(gx0.cpu().numpy(), rx) < 1e-8
+    assert relnorm(gnn.cpu().numpy(), rnn) < 1e-8
+    assert relnorm(gode.cpu().numpy(), rode) < 1e-8
+
+
+@pytest.mark.parametrize("name", ["t61_rand", "t241_pulses"])
+def test_adjoint_fp32_vs_fp64_oracle(hode, golden_dir, g0, name):
+    """BASELINE: adjoint gradients match the oracle to 1e-4 (fp32 kernel, default tolerances, vs the
+    fp64 oracle at tight tolerances)."""
+    x0, t, meal, tv, c = _adjoint_case(golden_dir, name)
+    ref = O.solve(x0, t, meal, tv, None, g0["ode"], g0["nn"], 64, 4, rtol=1e-10, atol=1e-12, dtype=np.float64,
+                  want_tape=True)
+    rx, rnn, rode = O.solve_bwd(ref, c)
+    dt = torch.float32
+    s = hode.solve_fwd(dev(x0, dt), dev(t, dt), dev(meal, dt), dev(tv, dt), None, dev(g0["ode"], dt),
+                       dev(g0["nn"], dt), 64, 4, rtol=1e-6, atol=1e-8, want_tape=True)
+    gx0, gnn, gode = hode.solve_bwd(s, dev(c, dt), want_gode=True)
+    assert relnorm(gx0.cpu().numpy(), rx) < 1e-4
+    assert relnorm(gnn.cpu().numpy(), rnn) < 1e-4
+    assert relnorm(gode.cpu().numpy(), rode) < 1e-4
+
+
+def test_adjoint_small_net_batched_time_and_sets(hode, golden_dir, g0_small):
+    g = np.load(os.path.join(golden_dir, "g4_batched_t_h32l2.npz"))
+    rng = np.random.default_rng(9)
+    c = rng.standard_normal((4, g["t"].shape[-1], 6))
+    dt = torch.float64
+    ref = O.solve(g["x0"], g["t"], g["meal"], g["tvns"], None, g0_small["ode"], g0_small["nn"], 32, 2, rtol=1e-8,
+                  atol=1e-10, dtype=np.float64, want_tape=True)
+    rx, rnn, _ = O.solve_bwd(ref, c)
+    s = hode.solve_fwd(dev(g["x0"], dt), dev(g["t"], dt), dev(g["meal"], dt), dev(g["tvns"], dt), None,
+                       dev(g0_small["ode"], dt), dev(g0_small["nn"], dt), 32, 2, rtol=1e-8, atol=1e-10, want_tape=True)
+    gx0, gnn, _ = hode.solve_bwd(s, dev(c, dt))
+    assert relnorm(gx0.cpu().numpy(), rx) < 1e-8 and relnorm(gnn.cpu().numpy(), rnn) < 1e-8
+    # two parameter sets: gradients land in their own slices
+    nn2 = np.concatenate([g0_small["nn"], g0_small["nn"]])
+    ode2 = np.concatenate([g0_small["ode"], g0_small["ode"]])
+    cat = lambda a: np.concatenate([a, a])  # noqa: E731
+    s2 = hode.solve_fwd(dev(cat(g["x0"]), dt), dev(cat(g["t"]), dt), dev(cat(g["meal"]), dt), dev(cat(g["tvns"]), dt),
+                        None, dev(ode2, dt), dev(nn2, dt), 32, 2, rtol=1e-8, atol=1e-10, n_sets=2, want_tape=True)
+    gx2, gnn2, _ = hode.solve_bwd(s2, dev(np.concatenate([c, 2 * c]), dt))
+    P = g0_small["nn"].size
+    assert relnorm(gnn2[:P].cpu().numpy(), rnn) < 1e-8 and relnorm(gnn2[P:].cpu().numpy(), 2 * rnn) < 1e-8
+    assert relnorm(gx2[4:].cpu().numpy(), 2 * rx) < 1e-8
+
+
+def test_adjoint_failed_trajectory_gradients(hode, golden_dir, g0):
+    """A trajectory that hits max_steps contributes only through the rows it wrote."""
+    x0, t, meal, tv, c = _adjoint_case(golden_dir, "t61_rand", B=2)
+    dt = torch.float64
+    ref = O.solve(x0, t, meal, tv, None, g0["ode"], g0["nn"], 64, 4, rtol=1e-6, atol=1e-8, dtype=np.float64,
+                  want_tape=True, max_steps=30)
+    rx, rnn, _ = O.solve_bwd(ref, c)
+    s = hode.solve_fwd(dev(x0, dt), dev(t, dt), dev(meal, dt), dev(tv, dt), None, dev(g0["ode"], dt),
+                       dev(g0["nn"], dt), 64, 4, rtol=1e-6, atol=1e-8, want_tape=True, max_steps=30)
+    assert int(s.status.max()) == 1
+    gx0, gnn, _ = hode.solve_bwd(s, dev(c, dt))
+    assert relnorm(gx0.cpu().numpy(), rx) < 1e-8 and relnorm(gnn.cpu().numpy(), rnn) < 1e-8
+
+
+def test_adam_step_vs_torch(hode):
+    """K6 vs clip_grad_norm_(., 5.0) + torch.optim.Adam (train/train_hybrid.py:255-261, 438-441)."""
+    torch.manual_seed(0)
+    n = 13510
+    p0 = torch.randn(n, device="cuda")
+    ref_p = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([ref_p], lr=1e-3)
+    p, m, v = p0.clone(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    for step in range(1, 6):
+        gsc = 10.0 if step % 2 else 0.01          # alternate clipped / unclipped
+        gr = torch.randn(n, device="cuda") * gsc
+        ref_p.grad = gr.clone()
+        torch.nn.utils.clip_grad_norm_([ref_p], 5.0)
+        opt.step()
+        hode.adam_step(p, gr, m, v, 1e-3, step=step, max_norm=5.0)
+        assert float((p - ref_p.detach()).abs().max()) < 2e-6
+    # grad_scale (all-reduce(sum) / world_size) is applied before the clip
+    p2, m2, v2 = p0.clone(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    p3, m3, v3 = p0.clone(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    gr = torch.randn(n, device="cuda")
+    hode.adam_step(p2, gr * 8, m2, v2, 1e-3, step=1, max_norm=5.0, grad_scale=0.125)
+    hode.adam_step(p3, gr, m3, v3, 1e-3, step=1, max_norm=5.0)
+    assert float((p2 - p3).abs().max()) < 1e-6
+
+
+def test_mse_fwd_bwd(hode):
+    torch.manual_seed(1)
+    for shape in [(7, 5, 6), (64, 241, 6), (3,)]:
+        y = torch.randn(*shape, device="cuda")
+        obs = torch.randn(*shape, device="cuda")
+        loss, gy = hode.mse_fwd_bwd(y, obs, 1.0 / y.numel())
+        ref = ((y.double() - obs.double()) ** 2).sum()
+        assert abs(float(loss) - float(ref)) < 1e-6 * float(ref) + 1e-12   # squares in fp32, sum in fp64
+        assert torch.allclose(gy, 2 * (y - obs) / y.numel(), rtol=1e-6, atol=1e-9)
