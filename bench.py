@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the hot path (BASELINE.json): patient-trajectories/s of the
+batched 6-state DP5(4) solve (ODE + 4x64 MLP residual, fp32, T = 241 grid points = 240 intervals).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One process per GPU.  A "step" is one pass of the hot path over one synthetic cohort shard
+(BASELINE config[1]: 4 096 patients per GPU, forward solve).  Inputs are resident in HBM before
+the timed region.  Weak scaling: every rank integrates its own 4 096-patient shard, no data-path
+collective in the forward path.  After the headline region the same shard is pushed through the
+TRAINING step of config[2]/[3] (forward with tape -> fused MSE -> adjoint -> one RCCL all-reduce
+of the 54 KB gradient buffer -> fused clip+Adam) and reported under "train_step".
+
+Rank 0 prints ONE JSON line.  `roofline` prices the solve kernel against the fp32 compute peak
+(the binding roof: ~5 000 flop/byte) and also carries the HBM reading;
+`cpu_baseline` times the oracle (C port of the same algorithm) on the host cores, N = 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "hybrid-ode-for-glp-1-and-glucose_amd"))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+H, L, T = 64, 4, 241
+FLOP_PER_RHS = 2 * (9 * 64 + 3 * 64 * 64 + 6 * 64) + 80      # 26 576: MLP MACs x2 + mechanistic terms
+FLOP_PER_STEP_ALGEBRA = 400                                   # stage sums, error norm, controller
+BYTES_FWD_PER_TRAJ = 24 + 964 + 964 + 241 * 6 * 4            # x0 + meal row + tVNS row + y  = 7 736 B
+BYTES_TRAIN_PER_TRAJ = 21_300
+PEAK_FP32_TFLOPS = 157.3                                      # MI355X_MICROARCH.md: fp32 vector == f32-MFMA dense peak
+PEAK_HBM_GBS = 8000.0
+
+
+def synth_weights(seed=0):
+    """G0-style weights: hidden layers xavier_normal(gain 0.1), zero biases, NON-zero output layer."""
+    g = torch.Generator().manual_seed(seed)
+    parts = []
+    dims = [(64, 9)] + [(64, 64)] * 3 + [(6, 64)]
+    for i, (o, n) in enumerate(dims):
+        std = 0.01 if i == len(dims) - 1 else 0.1 * (2.0 / (o + n)) ** 0.5
+        parts.append(torch.randn(o, n, generator=g) * std)
+        parts.append(torch.randn(o, generator=g) * 0.01 if i == len(dims) - 1 else torch.zeros(o))
+    return torch.cat([p.reshape(-1) for p in parts])
+
+
+ODE_DEFAULT = torch.tensor([0.0104, 0.025, 0.003, 5.0, 60.0, 0.1, 50.0, 80.0, 9.0, 7.0, 0.02, 0.01, 1000.0, 2.0,
+                            0.05, 0.001, 0.01])
+
+
+def synth_cohort(B, seed):
+    """4GI-style synthetic cohort (SURVEY 8d 'physio' regime): x0 = basal*(1+5% noise), 5-min grid over 20 h,
+    4 unit meal pulses per patient at random grid indices in 6..234, tVNS = 0."""
+    g = torch.Generator().manual_seed(seed)
+    base = torch.tensor([5.0, 60.0, 80.0, 10.0, 0.0, 1.0])
+    x0 = base * (1 + 0.05 * torch.randn(B, 6, generator=g))
+    t = (torch.arange(T, dtype=torch.float64) * (5.0 / 60.0)).float()
+    idx = torch.rand(B, 229, generator=g).argsort(dim=1)[:, :4] + 6
+    meal = torch.zeros(B, T).scatter_(1, idx, 1.0)
+    tvns = torch.zeros(B, T)
+    return x0, t, meal, tvns
+
+
+def cpu_baseline(sample, seconds_budget=20.0):
+    """Oracle (C port of the same grid-broken DP5(4), oracle/hode_oracle.c) on the host cores."""
+    from oracle import oracle as O
+    O.lib()
+    ncores = max(1, min(os.cpu_count() or 1, 16))     # the GPU box gives one GPU a 16-core share
+    x0, t, meal, tvns = (v.numpy() for v in synth_cohort(sample, 12345))
+    nn, ode = synth_weights().numpy(), ODE_DEFAULT.numpy()
+
+    def work(sl):
+        s = O.solve(x0[sl], t, meal[sl], tvns[sl], None, ode, nn, H, L, rtol=1e-6, atol=1e-8, dtype=np.float32)
+        return int(s.nsteps.sum())
+
+    chunks = [slice(i, min(i + 16, sample)) for i in range(0, sample, 16)]
+    work(slice(0, 4))
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(ncores) as ex:        # ctypes releases the GIL: real threads
+        list(ex.map(work, chunks))
+    dt = time.perf_counter() - t0
+    return {"value": sample / dt, "unit": "patient-trajectories/s", "cores": ncores, "kind": "port",
+            "sample": f"{sample} trajectories of the same synthetic cohort (T=241, fp32, rtol 1e-6/atol 1e-8), "
+                      f"C oracle, {ncores} threads, {dt:.1f} s wall",
+            "per_core": sample / dt / ncores}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--patients-per-gpu", type=int, default=4096)
+    ap.add_argument("--train-steps", type=int, default=5)
+    ap.add_argument("--cpu-sample", type=int, default=16384)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("for --gpus N > 1 launch with torch.distributed.run (one rank per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)      # "nccl" is RCCL on ROCm
+
+    import hode
+    hode.load()
+    B = args.patients_per_gpu
+    x0, t, meal, tvns = (v.to(dev) for v in synth_cohort(B, 1000 + rank))
+    nn_teacher = synth_weights(0).to(dev)
+    ode = ODE_DEFAULT.to(dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ------------------------------------------------------------------ headline: forward solve
+    def fwd_step():
+        return hode.solve_fwd(x0, t, meal, tvns, None, ode, nn_teacher, H, L, rtol=1e-6, atol=1e-8)
+
+    for _ in range(args.warmup):
+        sol = fwd_step()
+    barrier()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()                      # HIP events on torch's current stream == the stream the kernel runs on
+    for _ in range(args.steps):
+        sol = fwd_step()
+    e1.record()
+    barrier()
+    wall = time.perf_counter() - t0
+    kern_ms = e0.elapsed_time(e1) / args.steps
+    tm = torch.tensor([wall], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+    wall = float(tm)
+    nfev = float(sol.nfev.double().sum())
+    nsteps = float(sol.nsteps.double().sum())
+    ok = int((sol.status == 0).sum())
+    value = world * B * args.steps / wall
+
+    # ------------------------------------------------------------------ secondary: training step
+    train = None
+    if not args.no_train:
+        with torch.no_grad():
+            obs = fwd_step().y + 0.1 * torch.randn(B, T, 6, device=dev, generator=torch.Generator(dev).manual_seed(7 + rank))
+        student = (nn_teacher * (1 + 0.05 * torch.randn(nn_teacher.shape, generator=torch.Generator().manual_seed(99)).to(dev))).contiguous()
+        state = hode.train.TrainState(student.clone())
+        n_glob = world * B * T * 6
+
+        def compute(p):
+            ls, gnn, gode, _ = hode.train.hip_loss_and_grads(p, ode, x0, t, meal, tvns, obs, H, L, n_glob)
+            return ls, gnn, gode, B * T * 6
+
+        losses = [float(hode.train.train_step(state, compute)) for _ in range(2)]       # warm-up
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.train_steps):
+            loss = hode.train.train_step(state, compute)
+        barrier()
+        tw = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+        losses.append(float(loss))
+        train = {"metric": "patient-trajectories/s (fwd + adjoint + all-reduce + fused Adam)",
+                 "value": world * B * args.train_steps / float(tw), "ms_per_step": float(tw) / args.train_steps * 1e3,
+                 "steps": args.train_steps, "loss_first_last": [losses[0], losses[-1]],
+                 "collective": "1 x all_reduce(sum) of 13 529 fp32 (54 KB) per step" if world > 1 else "none (1 rank)"}
+
+    if rank == 0:
+        flops = nfev * FLOP_PER_RHS + nsteps * FLOP_PER_STEP_ALGEBRA
+        tflops = flops / (kern_ms * 1e-3) / 1e12
+        gbs = B * BYTES_FWD_PER_TRAJ / (kern_ms * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("solve_fwd_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "patient-trajectories/s (6-state, 240-step dopri5)", "value": value,
+            "unit": "patient-trajectories/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE config[1]: 4096-patient 4GI-style synthetic cohort per GPU, DP5(4) adaptive "
+                                   "(rtol 1e-6, atol 1e-8), ODE + 4x64 MLP residual, fp32, forward solve, T=241",
+                       "patients_per_gpu": B, "grid_points": T, "parallelism": f"patients sharded x{world}, no data-path collective",
+                       "trajectories_ok": ok, "mean_steps": nsteps / B, "mean_nfev": nfev / B},
+            "roofline": {"bound": "mfma", "bound_detail": "fp32 vector FMA (MFMA deliberately unused, north_star); the f32 "
+                         "MFMA dense peak equals the fp32 vector peak, 157.3 TFLOP/s",
+                         "achieved": tflops, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": tflops / PEAK_FP32_TFLOPS,
+                         "traffic": traffic, "kernel": "solve_fwd_kernel<float,4,DP54>", "kernel_ms": kern_ms,
+                         "algorithmic_flops_per_launch": flops,
+                         "hbm": {"achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
+                                 "algorithmic_bytes_per_launch": B * BYTES_FWD_PER_TRAJ}},
+        }
+        if train is not None:
+            out["train_step"] = train
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

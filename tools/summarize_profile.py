@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Condense a tools/profile_gpu.sh run (gpurun_out/prof_<tag>/) into the tracked files under profiles/:
+   profiles/<tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary (hode kernels + top others)
+   profiles/<tag>_pmc.json           per-kernel PMC averages (each counter group collected in its own pass)
+   profiles/pmc_traffic.json         HBM bytes per launch of the solve kernels, read by bench.py ("traffic")
+HBM bytes follow MI355X_MICROARCH.md (HBM section): FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE
+reports half of the bytes of a streaming read, so it is doubled; WRITE_SIZE is exact."""
+import collections, csv, glob, json, os, sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(root, "gpurun_out", f"prof_{tag}")
+dst = os.path.join(root, "profiles")
+os.makedirs(dst, exist_ok=True)
+
+
+def short(name):
+    name = name.replace("void ", "")
+    return name[:name.index("(")] if "(" in name else name
+
+
+stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
+rows = list(csv.DictReader(open(stats[0])))
+with open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w") as f:
+    f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --train-steps 2 --no-cpu-baseline\n")
+    f.write("kernel,calls,total_ns,avg_ns,pct,min_ns,max_ns\n")
+    for r in rows[:12]:
+        f.write(f"\"{short(r['Name'])[:90]}\",{r['Calls']},{r['TotalDurationNs']},{float(r['AverageNs']):.0f},{r['Percentage']},{r['MinNs']},{r['MaxNs']}\n")
+
+pmc = collections.defaultdict(dict)
+for fcsv in glob.glob(os.path.join(src, "pmc_*", "*", "*_counter_collection.csv")):
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(fcsv)):
+        agg[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k, d in agg.items():
+        if k.startswith("hode::"):
+            for c, v in d.items():
+                pmc[k][c] = sum(v) / len(v)
+            pmc[k].setdefault("_launches", len(next(iter(d.values()))))
+out = {"command": "rocprofv3 --pmc <group> -- python3 bench.py --steps 5 --warmup 2 --train-steps 2 --no-cpu-baseline",
+       "note": "per-launch averages; one rocprofv3 run per counter group (FETCH_SIZE and WRITE_SIZE in separate passes)",
+       "kernels": pmc}
+traffic = {}
+for k, d in pmc.items():
+    if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+        d["hbm_bytes_per_launch_corrected"] = (2 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024
+        if "solve_fwd" in k:
+            traffic["solve_fwd_hbm_bytes_per_launch"] = d["hbm_bytes_per_launch_corrected"]
+            traffic["solve_fwd_fetch_kib_raw"] = d["FETCH_SIZE"]
+            traffic["solve_fwd_write_kib_raw"] = d["WRITE_SIZE"]
+        if "solve_bwd" in k:
+            traffic["solve_bwd_hbm_bytes_per_launch"] = d["hbm_bytes_per_launch_corrected"]
+json.dump(out, open(os.path.join(dst, f"{tag}_pmc.json"), "w"), indent=1)
+traffic["source"] = f"profiles/{tag}_pmc.json (2*FETCH_SIZE + WRITE_SIZE) KiB, B=4096 T=241 fp32"
+json.dump(traffic, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
+print(open(os.path.join(dst, f"{tag}_kernel_stats.csv")).read())
+print(json.dumps(traffic, indent=1))
