@@ -233,6 +233,15 @@ template <typename R, int NL> struct MlpRegs {
 
 __host__ __device__ inline int nn_param_count(int H, int L) { return 9 * H + H + (L - 1) * (H * H + H) + 6 * H + 6; }
 
+// fp32 hidden layers use the "rotating operand" form (see mlp_hidden): register r = 16q + n of lane j holds
+// W_l[j][16q + ((j - n) & 15)], so that the activation can be fetched with a DPP row_ror:n operand of
+// the FMA itself instead of a v_readlane per element.  fp64 keeps the natural order (readlane path).
+template <typename R> __device__ __forceinline__ int wcol(int r, int lane)
+{
+    if constexpr (sizeof(R) == 4) return (r & 48) | ((lane - r) & 15);
+    else return r;
+}
+
 template <typename R, int NL>
 __device__ __forceinline__ void mlp_load(MlpRegs<R, NL> &W, const R *__restrict__ p, int H, int lane)
 {
@@ -247,21 +256,19 @@ __device__ __forceinline__ void mlp_load(MlpRegs<R, NL> &W, const R *__restrict_
 #pragma unroll
     for (int l = 0; l < NL - 1; ++l) {
         const R *row = p + (size_t)j * H;
-        if (H == kMaxH) {
-            if constexpr (sizeof(R) == 4) {
-                const float4 *r4 = reinterpret_cast<const float4 *>(row);
+        if constexpr (sizeof(R) == 4) {
+            // per-lane gather (one-time, L2-resident 16 KB matrix): column index depends on the lane
 #pragma unroll
-                for (int k = 0; k < kMaxH / 4; ++k) {
-                    float4 v = r4[k];
-                    W.wh[l][4 * k + 0] = v.x; W.wh[l][4 * k + 1] = v.y; W.wh[l][4 * k + 2] = v.z; W.wh[l][4 * k + 3] = v.w;
-                }
-            } else {
-                const double2 *r2 = reinterpret_cast<const double2 *>(row);
+            for (int k = 0; k < kMaxH; ++k) {
+                const int c = wcol<R>(k, lane);
+                W.wh[l][k] = ((c < H) ? live : R(0)) * row[(c < H) ? c : H - 1];
+            }
+        } else if (H == kMaxH) {
+            const double2 *r2 = reinterpret_cast<const double2 *>(row);
 #pragma unroll
-                for (int k = 0; k < kMaxH / 2; ++k) {
-                    double2 v = r2[k];
-                    W.wh[l][2 * k + 0] = v.x; W.wh[l][2 * k + 1] = v.y;
-                }
+            for (int k = 0; k < kMaxH / 2; ++k) {
+                double2 v = r2[k];
+                W.wh[l][2 * k + 0] = v.x; W.wh[l][2 * k + 1] = v.y;
             }
         } else {
 #pragma unroll
@@ -296,6 +303,15 @@ __device__ __forceinline__ float rpow(float a, float b) { return powf(a, b); }
 __device__ __forceinline__ double rpow(double a, double b) { return pow(a, b); }
 __device__ __forceinline__ float rlog(float a) { return logf(a); }
 __device__ __forceinline__ double rlog(double a) { return log(a); }
+// a / b.  fp32: v_rcp_f32 + one Newton step (|rel err| ~1e-7, 4 VALU instead of the ~10 of an IEEE
+// division); fp64 (parity runs): exact division.
+__device__ __forceinline__ float rdiv(float a, float b)
+{
+    float r = __builtin_amdgcn_rcpf(b);
+    r = __builtin_fmaf(__builtin_fmaf(-b, r, 1.0f), r, r);
+    return a * r;
+}
+__device__ __forceinline__ double rdiv(double a, double b) { return a / b; }
 __device__ __forceinline__ float rabs(float a) { return __builtin_fabsf(a); }
 __device__ __forceinline__ double rabs(double a) { return __builtin_fabs(a); }
 
@@ -304,6 +320,87 @@ template <typename R> __device__ __forceinline__ R gd_effect(const OdeP<R> &o, R
 {
     R u = rpow(gd, o.g), v = rpow(o.IGD_50, o.g);
     return u / (v + u);
+}
+
+// ------------------------------------------------------------------------------------------
+// One 64x64 hidden layer: out_j = b_j + sum_k W[j][k] h_k, lane j owns row j, h_k lives in lane k.
+//  fp32: the four 16-lane rows of h are first replicated to every row (1 v_permlane16_swap +
+//        2 v_permlane32_swap), then each FMA takes its activation through a DPP row_ror:n operand
+//        (lane i reads lane (i-n)&15 of its row): 64 v_fmac_f32_dpp + ~8 instead of 64 v_readlane +
+//        32 v_pk_fma.  Four independent accumulators.
+//  fp64: v_readlane broadcast (no 64-bit DPP FMA).
+// acc += row_ror:N(x) * w as ONE instruction.  hipcc (ROCm 7.2) selects the VOP3 v_fma_f32 for fmaf() and
+// its DPP-combine pass cannot fold a v_mov_b32_dpp into a VOP3 op on gfx9, so the VOP2 form is written out.
+// Hazard note (cdna_hip_programming.md 5.7: hipcc pads nothing around asm): a DPP operand needs 2 wait
+// states after the VALU that wrote it -- rows_replicate() ends with an explicit s_nop 1, and the
+// accumulator / weight operands are ordinary (interlocked) VALU operands.
+#define HODE_FMAC_ROR(N)                                                                                    \
+    template <> __device__ __forceinline__ float fmac_ror<N>(float acc, float x, float w)                   \
+    {                                                                                                       \
+        asm("v_fmac_f32_dpp %0, %1, %2 row_ror:" #N " row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(w)); \
+        return acc;                                                                                         \
+    }
+template <int N> __device__ __forceinline__ float fmac_ror(float acc, float x, float w);
+template <> __device__ __forceinline__ float fmac_ror<0>(float acc, float x, float w) { return __builtin_fmaf(x, w, acc); }
+HODE_FMAC_ROR(1) HODE_FMAC_ROR(2) HODE_FMAC_ROR(3) HODE_FMAC_ROR(4) HODE_FMAC_ROR(5) HODE_FMAC_ROR(6) HODE_FMAC_ROR(7)
+HODE_FMAC_ROR(8) HODE_FMAC_ROR(9) HODE_FMAC_ROR(10) HODE_FMAC_ROR(11) HODE_FMAC_ROR(12) HODE_FMAC_ROR(13)
+HODE_FMAC_ROR(14) HODE_FMAC_ROR(15)
+#undef HODE_FMAC_ROR
+__device__ __forceinline__ void rows_replicate(float h, float (&R)[4])
+{
+    auto s16 = __builtin_amdgcn_permlane16_swap((unsigned)f2i(h), (unsigned)f2i(h), false, false);   // [r0 r0 r2 r2] , [r1 r1 r3 r3]
+    auto a = __builtin_amdgcn_permlane32_swap(s16[0], s16[0], false, false);                           // [r0 x4] , [r2 x4]
+    auto b = __builtin_amdgcn_permlane32_swap(s16[1], s16[1], false, false);                           // [r1 x4] , [r3 x4]
+    R[0] = i2f((int)a[0]); R[2] = i2f((int)a[1]); R[1] = i2f((int)b[0]); R[3] = i2f((int)b[1]);
+    // 2 wait states between the swaps (VALU writes) and the first DPP read of R[] in the asm FMAs
+    asm volatile("s_nop 1" : "+v"(R[0]), "+v"(R[1]), "+v"(R[2]), "+v"(R[3]));
+}
+template <int N> __device__ __forceinline__ void mlp_hidden_step(const float (&w)[kMaxH], const float (&R)[4], float (&acc)[4])
+{
+    acc[0] = fmac_ror<N>(acc[0], R[0], w[0 * 16 + N]);
+    acc[1] = fmac_ror<N>(acc[1], R[1], w[1 * 16 + N]);
+    acc[2] = fmac_ror<N>(acc[2], R[2], w[2 * 16 + N]);
+    acc[3] = fmac_ror<N>(acc[3], R[3], w[3 * 16 + N]);
+    if constexpr (N < 15) mlp_hidden_step<N + 1>(w, R, acc);
+}
+__device__ __forceinline__ float mlp_hidden(const float (&w)[kMaxH], float bias, float h)
+{
+    float R[4];
+    rows_replicate(h, R);
+    float acc[4] = {bias, 0.f, 0.f, 0.f};
+    mlp_hidden_step<0>(w, R, acc);
+    return (acc[0] + acc[1]) + (acc[2] + acc[3]);
+}
+__device__ __forceinline__ double mlp_hidden(const double (&w)[kMaxH], double bias, double h)
+{
+    double acc0 = bias, acc1 = 0.0;
+#pragma unroll
+    for (int k = 0; k < kMaxH; k += 2) {
+        acc0 = rfma(w[k], lane_bcast(h, k), acc0);
+        acc1 = rfma(w[k + 1], lane_bcast(h, k + 1), acc1);
+    }
+    return acc0 + acc1;
+}
+
+// dW[j][k] += d_j * h_k in the register order of the weights (rotated for fp32, natural for fp64)
+template <int N> __device__ __forceinline__ void mlp_outer_step(float (&gw)[kMaxH], float d, const float (&R)[4])
+{
+    gw[0 * 16 + N] = fmac_ror<N>(gw[0 * 16 + N], R[0], d);
+    gw[1 * 16 + N] = fmac_ror<N>(gw[1 * 16 + N], R[1], d);
+    gw[2 * 16 + N] = fmac_ror<N>(gw[2 * 16 + N], R[2], d);
+    gw[3 * 16 + N] = fmac_ror<N>(gw[3 * 16 + N], R[3], d);
+    if constexpr (N < 15) mlp_outer_step<N + 1>(gw, d, R);
+}
+__device__ __forceinline__ void mlp_outer_acc(float (&gw)[kMaxH], float d, float hin)
+{
+    float R[4];
+    rows_replicate(hin, R);
+    mlp_outer_step<0>(gw, d, R);
+}
+__device__ __forceinline__ void mlp_outer_acc(double (&gw)[kMaxH], double d, double hin)
+{
+#pragma unroll
+    for (int k = 0; k < kMaxH; ++k) gw[k] = rfma(d, lane_bcast(hin, k), gw[k]);
 }
 
 // Activations kept by the backward pass: h[l] = relu output of hidden layer l+1 on lane j.
@@ -323,8 +420,8 @@ __device__ __forceinline__ R rhs_eval(const MlpRegs<R, NL> &W, const OdeP<R> &o,
     // ---- mechanistic part (models/ode_core.py:124-153), evaluated redundantly on every lane
     const R Pi = R(1) + o.rho * GLP1;
     const R dI = Pi * o.a_GI * (G - o.G_b) - o.k_I * (I - o.I_b);
-    const R dGlu = -(o.E_max * (GLP1 / (o.EC_50 + GLP1))) * (Glu - o.Glu_b);
-    const R dGLP1 = o.V_max * (G / (o.K_m + G)) - o.k_L * GLP1;
+    const R dGlu = -(o.E_max * rdiv(GLP1, o.EC_50 + GLP1)) * (Glu - o.Glu_b);
+    const R dGLP1 = o.V_max * rdiv(G, o.K_m + G) - o.k_L * GLP1;
     const R k_GE = o.k_GE0 * (R(1) - gde);
     const R dFFA = -o.p_7 * FFA - o.p_8 * I * FFA + o.p_9 * G * FFA;
     const R dG = meal - R(0.01) * (I - o.I_b) + R(0.005) * (Glu - o.Glu_b) - k_GE * G;
@@ -345,13 +442,7 @@ __device__ __forceinline__ R rhs_eval(const MlpRegs<R, NL> &W, const OdeP<R> &o,
     if constexpr (KEEP) acts->h[0] = h;
 #pragma unroll
     for (int l = 0; l < NL - 1; ++l) {
-        R acc0 = W.b[l + 1], acc1 = R(0);
-#pragma unroll
-        for (int k = 0; k < kMaxH; k += 2) {
-            acc0 = rfma(W.wh[l][k], lane_bcast(h, k), acc0);
-            acc1 = rfma(W.wh[l][k + 1], lane_bcast(h, k + 1), acc1);
-        }
-        h = rmax0(acc0 + acc1);
+        h = rmax0(mlp_hidden(W.wh[l], W.b[l + 1], h));
         if constexpr (KEEP) acts->h[l + 1] = h;
     }
     R p[6];
@@ -406,8 +497,10 @@ __device__ __forceinline__ void grads_flush(const MlpGrads<R, NL> &g, R *__restr
     for (int l = 0; l < NL - 1; ++l) {
         if (live) {
 #pragma unroll
-            for (int k = 0; k < kMaxH; ++k)
-                if (k < H) atomic_add(gp + (size_t)lane * H + k, g.wh[l][k]);
+            for (int k = 0; k < kMaxH; ++k) {
+                const int c = wcol<R>(k, lane);            // register k of lane j is column c (rotated order in fp32)
+                if (c < H) atomic_add(gp + (size_t)lane * H + c, g.wh[l][k]);
+            }
         }
         gp += (size_t)H * H;
         if (live) atomic_add(gp + lane, g.b[l + 1]);
@@ -430,7 +523,7 @@ __device__ __forceinline__ void wt_store(R *__restrict__ wt, const MlpRegs<R, NL
     for (int l = 0; l < NL - 1; ++l)
 #pragma unroll
         for (int k = 0; k < kMaxH; ++k)
-            wt[(size_t)l * kMaxH * kMaxH + ((lane >> 2) * kMaxH + k) * 4 + (lane & 3)] = W.wh[l][k];
+            wt[(size_t)l * kMaxH * kMaxH + ((lane >> 2) * kMaxH + wcol<R>(k, lane)) * 4 + (lane & 3)] = W.wh[l][k];
 }
 
 template <typename R> struct alignas(sizeof(R) * 4) Vec4 { R v[4]; };
@@ -502,8 +595,7 @@ __device__ __forceinline__ R rhs_vjp(const MlpRegs<R, NL> &W, const R *__restric
     for (int l = NL - 1; l >= 1; --l) {           // hidden matrix l-1 maps acts.h[l-1] -> acts.h[l]
         const R hin = acts.h[l - 1];
         g.b[l] += d;
-#pragma unroll
-        for (int k = 0; k < kMaxH; ++k) g.wh[l - 1][k] = rfma(d, lane_bcast(hin, k), g.wh[l - 1][k]);
+        mlp_outer_acc(g.wh[l - 1], d, hin);         // dW_l[j][:] += delta_j * h_{l-1}[:]
         const Vec4<R> *wt4 = reinterpret_cast<const Vec4<R> *>(wt + (size_t)(l - 1) * kMaxH * kMaxH);
         R acc0 = R(0), acc1 = R(0);
 #pragma unroll 2
