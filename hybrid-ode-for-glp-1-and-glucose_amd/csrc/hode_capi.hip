@@ -31,7 +31,9 @@ int solve_fwd(void *stream, int B, int T, const R *x0, const R *t, int t_batched
     a.rtol = (R)rtol; a.atol = (R)atol;
     a.y = y; a.status = status; a.nsteps = nsteps; a.nfev = nfev;
     a.tape = (R *)tape;
-    a.tape_seg = tape ? (int32_t *)((char *)tape + (size_t)B * max_steps * 8 * sizeof(R)) : nullptr;
+    a.tape_seg = tape ? (int32_t *)((char *)tape + tape_seg_offset(B, max_steps, sizeof(R))) : nullptr;
+    a.tape_stage = tape ? (R *)((char *)tape + tape_stage_offset(B, max_steps, sizeof(R))) : nullptr;
+    a.L = L;
     return launch_solve_fwd<R>((hipStream_t)stream, a, L, method);
 }
 
@@ -67,7 +69,8 @@ int solve_bwd(void *stream, int B, int T, const R *t, int t_batched, const R *me
     a.t = t; a.meal = meal; a.tvns = tvns; a.gd = gd; a.ode_p = ode_p; a.nn_p = nn_p;
     a.nsteps = nsteps; a.status = status;
     a.tape = (const R *)tape;
-    a.tape_seg = (const int32_t *)((const char *)tape + (size_t)B * max_steps * 8 * sizeof(R));
+    a.tape_seg = (const int32_t *)((const char *)tape + tape_seg_offset(B, max_steps, sizeof(R)));
+    a.tape_stage = (const R *)((const char *)tape + tape_stage_offset(B, max_steps, sizeof(R)));
     a.gy = gy; a.gx0 = gx0; a.gnn = gnn; a.gode = gode;
     return launch_solve_bwd<R>((hipStream_t)stream, a, L, method);
 }
@@ -94,10 +97,10 @@ const char *hode_version(void) { return "hode 0.1.0 (gfx950; wave-per-trajectory
 
 int hode_nn_param_count(int H, int L) { return (H < 1 || L < 1) ? HODE_EINVAL : nn_param_count(H, L); }
 
-size_t hode_tape_bytes(int B, int max_steps, int elem_size)
+size_t hode_tape_bytes(int B, int max_steps, int elem_size, int L)
 {
-    if (B < 0 || max_steps < 0 || (elem_size != 4 && elem_size != 8)) return 0;
-    return (size_t)B * (size_t)max_steps * (8 * (size_t)elem_size + sizeof(int32_t));
+    if (B < 0 || max_steps < 0 || (elem_size != 4 && elem_size != 8) || L < 1 || L > HODE_MAX_LAYERS) return 0;
+    return tape_total_bytes(B, max_steps, (size_t)elem_size, L);
 }
 
 int hode_rhs_fwd_f32(void *stream, int B, const float *x, const float *t, const float *meal, const float *tvns,

@@ -514,29 +514,166 @@ __device__ __forceinline__ void grads_flush(const MlpGrads<R, NL> &g, R *__restr
     if (lane < 6) atomic_add(gp + lane, g.b5);
 }
 
-// LDS image of the TRANSPOSED hidden matrices: element W_l[j][k] at ((j/4)*64 + k)*4 + (j%4), so
-// lane k fetches W_l[4jj..4jj+3][k] with one conflict-free 16/32-byte read.
-template <typename R, int NL>
-__device__ __forceinline__ void wt_store(R *__restrict__ wt, const MlpRegs<R, NL> &W, int lane)
+// LDS image of the TRANSPOSED hidden matrices in "rotating operand" order (shared by a workgroup):
+//   wt[l][r >> 2][k][r & 3] = W_l[ (r & 48) | ((k - r) & 15) ][k]        r = 16q + n, k = lane
+// so that delta_{l-1}[k] = sum_j W_l[j][k] delta_l[j] becomes, on lane k,
+//   sum_r  row_ror:n( rows-replicated delta_l )[k] * wt[l][r][k]
+// i.e. 64 v_fmac_f32_dpp fed by 16 conflict-free 16-byte LDS reads per layer (fp32).  The fp64
+// instantiation (parity runs) uses the same image with v_readlane broadcasts.
+template <typename R>
+__device__ __forceinline__ void wt_rot_store(R *__restrict__ wt, const R *__restrict__ nn_p, int H, int NLm1, int tid,
+                                             int nthreads)
 {
-#pragma unroll
-    for (int l = 0; l < NL - 1; ++l)
-#pragma unroll
-        for (int k = 0; k < kMaxH; ++k)
-            wt[(size_t)l * kMaxH * kMaxH + ((lane >> 2) * kMaxH + wcol<R>(k, lane)) * 4 + (lane & 3)] = W.wh[l][k];
+    const R *Wl = nn_p + 9 * H + H;
+    for (int l = 0; l < NLm1; ++l) {
+        for (int i = tid; i < kMaxH * kMaxH; i += nthreads) {
+            const int r = ((i >> 8) << 2) | (i & 3), k = (i >> 2) & 63;
+            const int j = (r & 48) | ((k - r) & 15);
+            wt[(size_t)l * kMaxH * kMaxH + i] = (j < H && k < H) ? Wl[(size_t)j * H + k] : R(0);
+        }
+        Wl += (size_t)H * H + H;
+    }
 }
 
 template <typename R> struct alignas(sizeof(R) * 4) Vec4 { R v[4]; };
 
-// VJP of rhs_eval.  kb = lane-distributed cotangent of f; returns the lane-distributed cotangent
-// of the state, accumulates parameter gradients.  acts = activations saved by rhs_eval<KEEP>.
-//   go[17] (GODE): wave-uniform accumulators of d/d(ode constants)
-template <typename R, int NL, bool GODE, bool GT>
-__device__ __forceinline__ R rhs_vjp(const MlpRegs<R, NL> &W, const R *__restrict__ wt, const OdeP<R> &o, R t, R Y,
-                                     R meal, R tvns, R gde, R gd_in, bool use_gd, int lane,
-                                     const MlpActs<R, NL> &acts, R kb, MlpGrads<R, NL> &g, R (&go)[17], R *gt_out)
+// delta_prev = W^T delta for one hidden layer from the LDS image above
+template <int RR> __device__ __forceinline__ void wt_mul_step(const Vec4<float> *__restrict__ wt4, int lane, const float (&Rr)[4],
+                                                              float (&acc)[4])
 {
-    (void)meal;
+    const Vec4<float> w = wt4[RR * kMaxH + lane];
+    constexpr int q = RR >> 2, n0 = (RR & 3) * 4;
+    acc[0] = fmac_ror<n0 + 0>(acc[0], Rr[q], w.v[0]);
+    acc[1] = fmac_ror<n0 + 1>(acc[1], Rr[q], w.v[1]);
+    acc[2] = fmac_ror<n0 + 2>(acc[2], Rr[q], w.v[2]);
+    acc[3] = fmac_ror<n0 + 3>(acc[3], Rr[q], w.v[3]);
+    if constexpr ((RR & 3) == 3) __builtin_amdgcn_sched_barrier(0);     // keep at most 4 LDS reads hoisted
+    if constexpr (RR < 15) wt_mul_step<RR + 1>(wt4, lane, Rr, acc);
+}
+__device__ __forceinline__ float wt_mul(const float *__restrict__ wt, int lane, float d)
+{
+    float Rr[4];
+    rows_replicate(d, Rr);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    wt_mul_step<0>(reinterpret_cast<const Vec4<float> *>(wt), lane, Rr, acc);
+    return (acc[0] + acc[1]) + (acc[2] + acc[3]);
+}
+__device__ __forceinline__ double wt_mul(const double *__restrict__ wt, int lane, double d)
+{
+    const Vec4<double> *wt4 = reinterpret_cast<const Vec4<double> *>(wt);
+    double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll 2
+    for (int rr = 0; rr < kMaxH / 4; ++rr) {
+        const Vec4<double> w = wt4[rr * kMaxH + lane];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int r = 4 * rr + c;
+            const int j = (r & 48) | ((lane - r) & 15);            // the lane whose delta this entry multiplies
+            const double dj = __shfl(d, j);
+            if (c & 1) acc1 = rfma(w.v[c], dj, acc1); else acc0 = rfma(w.v[c], dj, acc0);
+        }
+    }
+    return acc0 + acc1;
+}
+
+// ------------------------------------------------------------------------------------------
+// First/last-layer weights and their gradient accumulators ("edge" parameters: W1[.,9], b_1..b_NL,
+// Wout[6,.], bout) behind a small policy, so that the adjoint kernel can keep them in LDS and spend
+// its registers on the 3 x 64 hidden-matrix accumulators:
+//   EdgeRegs : everything in VGPRs (K5, fp64 parity builds)
+//   EdgeLds  : weights in a workgroup-shared LDS table, accumulators in a wave-private LDS table
+//              (read-modify-write; the table is private to the wave, so no atomics are needed)
+// slots: 0..8 W1 columns, 9..9+NL-1 hidden biases, then 6 Wout rows, then bout (lane o < 6).
+template <int NL> struct EdgeSlots { static constexpr int w1 = 0, b = 9, w5 = 9 + NL, b5 = 15 + NL, count = 16 + NL; };
+
+template <typename R, int NL> struct EdgeRegs {
+    R w[EdgeSlots<NL>::count];
+    R gacc[EdgeSlots<NL>::count];
+    __device__ __forceinline__ R W(int slot) const { return w[slot]; }
+    __device__ __forceinline__ void add(int slot, R v) { gacc[slot] += v; }
+    __device__ __forceinline__ void fma(int slot, R a, R b) { gacc[slot] = rfma(a, b, gacc[slot]); }
+    __device__ __forceinline__ R G(int slot) const { return gacc[slot]; }
+};
+template <typename R, int NL> struct EdgeLds {
+    const R *w;      // [slots][64] shared by the workgroup
+    R *gacc;         // [slots][64] private to the wave
+    int lane;
+    __device__ __forceinline__ R W(int slot) const { return w[slot * kWave + lane]; }
+    // wave-private table: a plain read-modify-write is safe and runs at the full LDS rate
+    // (ds_add_f32 serialises per lane: measured 2.5x slower for the whole kernel)
+    __device__ __forceinline__ void add(int slot, R v) { gacc[slot * kWave + lane] += v; }
+    __device__ __forceinline__ void fma(int slot, R a, R b) { gacc[slot * kWave + lane] = rfma(a, b, gacc[slot * kWave + lane]); }
+    __device__ __forceinline__ R G(int slot) const { return gacc[slot * kWave + lane]; }
+};
+// edge weights of one parameter set into a [slots][64] table (weights only; accumulators start at 0)
+template <typename R, int NL>
+__device__ __forceinline__ void edge_table_store(R *__restrict__ tab, const R *__restrict__ p, int H, int tid, int nthreads)
+{
+    using S = EdgeSlots<NL>;
+    const R *pout = p + 9 * H + H + (size_t)(NL - 1) * ((size_t)H * H + H);
+    for (int i = tid; i < S::count * kWave; i += nthreads) {
+        const int slot = i >> 6, j = i & 63;
+        R v = R(0);
+        if (j < H) {
+            if (slot < S::b) v = p[j * 9 + slot];
+            else if (slot >= S::w5 && slot < S::b5) v = pout[(slot - S::w5) * H + j];
+        }
+        tab[i] = v;            // bias slots hold no weight the VJP needs
+    }
+}
+// flush the edge accumulators into the flat gradient vector
+template <typename R, int NL, typename Edge>
+__device__ __forceinline__ void edge_flush(const Edge &e, R *__restrict__ gp, int H, int lane)
+{
+    using S = EdgeSlots<NL>;
+    const bool live = lane < H;
+    if (live) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) atomic_add(gp + lane * 9 + i, e.G(S::w1 + i));
+        atomic_add(gp + 9 * H + lane, e.G(S::b + 0));
+    }
+    R *q = gp + 9 * H + H;
+#pragma unroll
+    for (int l = 1; l < NL; ++l) {
+        q += (size_t)H * H;
+        if (live) atomic_add(q + lane, e.G(S::b + l));
+        q += H;
+    }
+    if (live) {
+#pragma unroll
+        for (int o = 0; o < 6; ++o) atomic_add(q + o * H + lane, e.G(S::w5 + o));
+    }
+    if (lane < 6) atomic_add(q + 6 * H + lane, e.G(S::b5));
+}
+// hidden-matrix accumulators only
+template <typename R, int NL>
+__device__ __forceinline__ void hidden_flush(const R (&wh)[(NL > 1) ? NL - 1 : 1][kMaxH], R *__restrict__ gp, int H, int lane)
+{
+    const bool live = lane < H;
+    R *q = gp + 9 * H + H;
+#pragma unroll
+    for (int l = 0; l < NL - 1; ++l) {
+        if (live) {
+#pragma unroll
+            for (int k = 0; k < kMaxH; ++k) {
+                const int c = wcol<R>(k, lane);            // register k of lane j is column c (rotated order in fp32)
+                if (c < H) atomic_add(q + (size_t)lane * H + c, wh[l][k]);
+            }
+        }
+        q += (size_t)H * H + H;
+    }
+}
+
+// VJP of rhs_eval.  kb = cotangent of f (replicated layout); returns the cotangent of the state in the
+// same layout and accumulates parameter gradients.  acts = activations of this evaluation (from
+// rhs_eval<KEEP> or from the stage tape).  Needs only the first/last layer weights in registers;
+// the hidden matrices come transposed from LDS (wt).   go[17] (GODE): d/d(ode constants), wave-uniform.
+template <typename R, int NL, bool GODE, bool GT, typename Edge>
+__device__ __forceinline__ R rhs_vjp(Edge &e, R (&gwh)[(NL > 1) ? NL - 1 : 1][kMaxH], const R *__restrict__ wt,
+                                     const OdeP<R> &o, R t, R Y, R tvns, R gde, R gd_in, bool use_gd, int lane,
+                                     const MlpActs<R, NL> &acts, R kb, R (&go)[17], R *gt_out)
+{
+    using S = EdgeSlots<NL>;
     const R G = lane_bcast(Y, 0), I = lane_bcast(Y, 1), Glu = lane_bcast(Y, 2), GLP1 = lane_bcast(Y, 3),
             GE = lane_bcast(Y, 4), FFA = lane_bcast(Y, 5);
     const R lG = lane_bcast(kb, 0), lI = lane_bcast(kb, 1), lGlu = lane_bcast(kb, 2), lGLP = lane_bcast(kb, 3),
@@ -545,7 +682,7 @@ __device__ __forceinline__ R rhs_vjp(const MlpRegs<R, NL> &W, const R *__restric
     const R Pi = R(1) + o.rho * GLP1;
     const R den1 = o.EC_50 + GLP1, den2 = o.K_m + G;
     const R k_GE = o.k_GE0 * (R(1) - gde);
-    const R r1 = R(1) / den1, r2 = R(1) / den2;
+    const R r1 = rdiv(R(1), den1), r2 = rdiv(R(1), den2);
     const R oG = -k_GE * lG + Pi * o.a_GI * lI + o.V_max * o.K_m * r2 * r2 * lGLP + o.p_9 * FFA * lF;
     const R oI = R(-0.01) * lG - o.k_I * lI - o.p_8 * FFA * lF;
     const R oGlu = R(0.005) * lG - o.E_max * GLP1 * r1 * lGlu;
@@ -577,56 +714,52 @@ __device__ __forceinline__ R rhs_vjp(const MlpRegs<R, NL> &W, const R *__restric
     }
     // ---- MLP backward
     const R hl = acts.h[NL - 1];
-    g.b5 += kb;                                  // lane o < 6 holds d bout[o] (other groups hold copies)
-    g.w5[0] = rfma(lG, hl, g.w5[0]);
-    g.w5[1] = rfma(lI, hl, g.w5[1]);
-    g.w5[2] = rfma(lGlu, hl, g.w5[2]);
-    g.w5[3] = rfma(lGLP, hl, g.w5[3]);
-    g.w5[4] = rfma(lGE, hl, g.w5[4]);
-    g.w5[5] = rfma(lF, hl, g.w5[5]);
-    R d = W.w5[0] * lG;
-    d = rfma(W.w5[1], lI, d);
-    d = rfma(W.w5[2], lGlu, d);
-    d = rfma(W.w5[3], lGLP, d);
-    d = rfma(W.w5[4], lGE, d);
-    d = rfma(W.w5[5], lF, d);
+    // fetch the six output-layer weights in one batch (LDS policy: six reads in flight, one wait)
+    const R w50 = e.W(S::w5 + 0), w51 = e.W(S::w5 + 1), w52 = e.W(S::w5 + 2), w53 = e.W(S::w5 + 3),
+            w54 = e.W(S::w5 + 4), w55 = e.W(S::w5 + 5);
+    R d = w50 * lG;
+    d = rfma(w51, lI, d);
+    d = rfma(w52, lGlu, d);
+    d = rfma(w53, lGLP, d);
+    d = rfma(w54, lGE, d);
+    d = rfma(w55, lF, d);
+    e.add(S::b5, kb);                            // lane o < 6 holds d bout[o] (other groups hold copies)
+    e.fma(S::w5 + 0, lG, hl);
+    e.fma(S::w5 + 1, lI, hl);
+    e.fma(S::w5 + 2, lGlu, hl);
+    e.fma(S::w5 + 3, lGLP, hl);
+    e.fma(S::w5 + 4, lGE, hl);
+    e.fma(S::w5 + 5, lF, hl);
     d = (hl > R(0)) ? d : R(0);
 #pragma unroll
     for (int l = NL - 1; l >= 1; --l) {           // hidden matrix l-1 maps acts.h[l-1] -> acts.h[l]
         const R hin = acts.h[l - 1];
-        g.b[l] += d;
-        mlp_outer_acc(g.wh[l - 1], d, hin);         // dW_l[j][:] += delta_j * h_{l-1}[:]
-        const Vec4<R> *wt4 = reinterpret_cast<const Vec4<R> *>(wt + (size_t)(l - 1) * kMaxH * kMaxH);
-        R acc0 = R(0), acc1 = R(0);
-#pragma unroll 2
-        for (int jj = 0; jj < kMaxH / 4; ++jj) {          // partial unroll keeps only two 16-byte reads in flight
-            const Vec4<R> w = wt4[jj * kMaxH + lane];
-            acc0 = rfma(w.v[0], lane_bcast(d, 4 * jj + 0), acc0);
-            acc1 = rfma(w.v[1], lane_bcast(d, 4 * jj + 1), acc1);
-            acc0 = rfma(w.v[2], lane_bcast(d, 4 * jj + 2), acc0);
-            acc1 = rfma(w.v[3], lane_bcast(d, 4 * jj + 3), acc1);
-        }
-        d = (hin > R(0)) ? (acc0 + acc1) : R(0);
+        e.add(S::b + l, d);
+        mlp_outer_acc(gwh[l - 1], d, hin);           // dW_l[j][:] += delta_j * h_{l-1}[:]
+        const R dp = wt_mul(wt + (size_t)(l - 1) * kMaxH * kMaxH, lane, d);
+        d = (hin > R(0)) ? dp : R(0);
     }
-    g.b[0] += d;
-    g.w1[0] = rfma(d, t, g.w1[0]);
-    g.w1[1] = rfma(d, G, g.w1[1]);
-    g.w1[2] = rfma(d, I, g.w1[2]);
-    g.w1[3] = rfma(d, Glu, g.w1[3]);
-    g.w1[4] = rfma(d, GLP1, g.w1[4]);
-    g.w1[5] = rfma(d, GE, g.w1[5]);
-    g.w1[6] = rfma(d, FFA, g.w1[6]);
-    g.w1[7] = rfma(d, GLP1, g.w1[7]);
-    g.w1[8] = rfma(d, tvns, g.w1[8]);
+    e.add(S::b + 0, d);
+    e.fma(S::w1 + 0, d, t);
+    e.fma(S::w1 + 1, d, G);
+    e.fma(S::w1 + 2, d, I);
+    e.fma(S::w1 + 3, d, Glu);
+    e.fma(S::w1 + 4, d, GLP1);
+    e.fma(S::w1 + 5, d, GE);
+    e.fma(S::w1 + 6, d, FFA);
+    e.fma(S::w1 + 7, d, GLP1);
+    e.fma(S::w1 + 8, d, tvns);
+    const R w11 = e.W(S::w1 + 1), w12 = e.W(S::w1 + 2), w13 = e.W(S::w1 + 3), w14 = e.W(S::w1 + 4), w15 = e.W(S::w1 + 5),
+            w16 = e.W(S::w1 + 6), w17 = e.W(S::w1 + 7);
     R p[6];
-    p[0] = W.w1[1] * d;
-    p[1] = W.w1[2] * d;
-    p[2] = W.w1[3] * d;
-    p[3] = (W.w1[4] + W.w1[7]) * d;               // GLP1 feeds inputs 4 and 7
-    p[4] = W.w1[5] * d;
-    p[5] = W.w1[6] * d;
+    p[0] = w11 * d;
+    p[1] = w12 * d;
+    p[2] = w13 * d;
+    p[3] = (w14 + w17) * d;                       // GLP1 feeds inputs 4 and 7
+    p[4] = w15 * d;
+    p[5] = w16 * d;
     const R nn = wave_reduce6_to_lanes(p, lane);
-    if constexpr (GT) *gt_out = wave_allsum(W.w1[0] * d);
+    if constexpr (GT) *gt_out = wave_allsum(e.W(S::w1 + 0) * d);
     return (c8 < 6) ? (mech + nn) : R(0);
 }
 

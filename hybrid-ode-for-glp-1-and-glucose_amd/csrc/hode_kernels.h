@@ -14,6 +14,8 @@ template <typename R> struct SolveArgs {
     int32_t *status, *nsteps, *nfev;
     R *tape;            // [B][max_steps][8] = {t, h, y0..y5}
     int32_t *tape_seg;  // [B][max_steps] grid interval of each accepted step
+    R *tape_stage;      // [B][max_steps][6 stages][L+1][64]: layer activations + stage state of every accepted step
+    int L;
 };
 
 template <typename R> struct AdjArgs {
@@ -22,6 +24,7 @@ template <typename R> struct AdjArgs {
     const int32_t *nsteps, *status;
     const R *tape;
     const int32_t *tape_seg;
+    const R *tape_stage;
     const R *gy;
     R *gx0, *gnn, *gode;
 };
@@ -42,5 +45,17 @@ int launch_adam(hipStream_t s, int64_t n, float *p, const float *g, float *m, fl
                 float b2, float eps, int step, float max_norm, float grad_scale, float wd, void *scratch);
 int launch_mse(hipStream_t s, int64_t n, const float *y, const float *obs, float scale, double *loss, float *gy);
 int launch_selftest(hipStream_t s, int32_t *out);
+
+// tape = entries | interval indices | (256-byte aligned) stage tape
+inline size_t tape_seg_offset(int B, int max_steps, size_t elem) { return (size_t)B * max_steps * 8 * elem; }
+inline size_t tape_stage_offset(int B, int max_steps, size_t elem)
+{
+    size_t o = tape_seg_offset(B, max_steps, elem) + (size_t)B * max_steps * sizeof(int32_t);
+    return (o + 255) & ~(size_t)255;
+}
+inline size_t tape_total_bytes(int B, int max_steps, size_t elem, int L)
+{
+    return tape_stage_offset(B, max_steps, elem) + (size_t)B * max_steps * 6 * (L + 1) * 64 * elem;
+}
 
 }  // namespace hode

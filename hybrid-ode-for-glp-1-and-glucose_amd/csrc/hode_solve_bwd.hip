@@ -4,19 +4,25 @@
 // 234-237, 248).  north_star asks for adjoint backprop, so this kernel
 // differentiates the discrete scheme the forward kernel ran ("discretise-then-differentiate"):
 // it walks the tape of accepted steps backwards, recomputes the Runge-Kutta stages of each step
-// and pulls the cotangent through them.  Step sizes are treated as constants.
+// and pulls the cotangent through them.  Step sizes are treated as constants.  (Stages are replayed
+// from the stage tape, see below.)
 // CPU restatement: oracle/hode_oracle_impl.h (hode_oracle_solve_bwd).
 //
 // Mapping: one trajectory per wavefront, one hidden unit per lane (see hode_device.h).
-//   * lane j keeps row j of the weights AND row j of the gradient accumulators in VGPRs
-//     (2 x 211 registers in fp32 -> one wave per SIMD);
-//   * dW_l[j][:] += delta_l[j] * h_{l-1}[:]  is 64 FMAs with h broadcast by v_readlane;
+//   * the forward recorded, for every stage of every accepted step, the layer activations and the
+//     stage state on the "stage tape" in HBM (7.7 KB per step in fp32): the adjoint re-reads them
+//     (coalesced 256-byte rows, prefetched one stage ahead) instead of recomputing the forward --
+//     a memory-for-compute trade that 288 GB / 8 TB/s of HBM3E make cheap;
+//   * lane j keeps row j of the gradient accumulators in VGPRs (211 registers in fp32) plus the
+//     first/last layer weights (15): 2 waves per SIMD;
+//   * dW_l[j][:] += delta_l[j] * h_{l-1}[:]  is 64 v_fmac_f32_dpp (rotating-operand form);
 //   * delta_{l-1} = W_l^T delta_l reads the transposed matrices from an LDS image shared by the
-//     4 waves of the workgroup (lane k fetches W_l[4jj..4jj+3][k] with one 16-byte read);
+//     8 waves of the workgroup (one 16-byte read per 4 FMAs, again with DPP row_ror operands);
 //   * a wave loops over several trajectories and keeps accumulating, so the cross-trajectory
 //     reduction costs one atomic flush per wave at the end (13.5k atomics per wave).
 #include "hode_device.h"
 #include "hode_kernels.h"
+#include <type_traits>
 
 namespace hode {
 
@@ -26,55 +32,82 @@ template <typename R> __device__ __forceinline__ R inp_at_b(const R *__restrict_
     return (mode == 1) ? p[b] : p[(size_t)b * T + k];
 }
 
-// LDS layout of the adjoint workgroup (4 waves):
-//   wt    [(NL-1)][64*64]   transposed hidden matrices (shared)
-//   rows  [8][64]           tableau rows     A[s][lane>>3]          (shared)
-//   rowsT [8][64]           transposed rows  A[lane>>3][s], row 7 = 1 (shared)
-//   acts  [4 waves][6 stages][NL][64]   activations of the recomputed stages (per wave)
+// LDS layout of the adjoint workgroup (kBwdWaves waves sharing one parameter set):
+//   wt    [(NL-1)][64*64]   transposed hidden matrices, rotating-operand order (hode_device.h: wt_rot_store)
+//   rowsT [8][64]           transposed tableau rows A[lane>>3][s]; row 7 = 1 for the solution stages
+constexpr int kBwdWaves = 8;
+//   edgeW [16+NL][64]       first/last layer weights (fp32 build; shared)
+//   edgeG [waves][16+NL][64] first/last layer gradient accumulators (fp32 build; per wave, ds_add_f32)
+template <typename R> constexpr bool kEdgeLds = (sizeof(R) == 4);
 template <typename R, int NL> __host__ __device__ constexpr size_t bwd_lds_elems()
 {
-    return (size_t)(NL > 1 ? NL - 1 : 1) * kMaxH * kMaxH + 2 * 8 * kWave + (size_t)4 * 6 * NL * kWave;
+    return (size_t)(NL > 1 ? NL - 1 : 1) * kMaxH * kMaxH + 8 * kWave +
+           (kEdgeLds<R> ? (size_t)(1 + kBwdWaves) * EdgeSlots<NL>::count * kWave : 0);
 }
 
+// The adjoint reads, for every stage of every accepted step, what the forward recorded on the stage
+// tape (layer activations + stage state): it never recomputes the forward.  Registers therefore hold
+// only the gradient accumulators (211) + the first/last layer weights (15): 2 waves per SIMD in fp32.
 template <typename R, int NL, bool GODE>
-__global__ __launch_bounds__(256, 1) void solve_bwd_kernel(const AdjArgs<R> a, const int method)
+__global__ __launch_bounds__(64 * kBwdWaves, (sizeof(R) == 4 ? 2 : 1)) void solve_bwd_kernel(const AdjArgs<R> a, const int method)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     R *wt = reinterpret_cast<R *>(smem_raw);
-    R *rows = wt + (size_t)(NL > 1 ? NL - 1 : 1) * kMaxH * kMaxH;
-    R *rowsT = rows + 8 * kWave;
+    R *rowsT = wt + (size_t)(NL > 1 ? NL - 1 : 1) * kMaxH * kMaxH;
 
     const int lane = threadIdx.x & 63;
     const int c8 = lane & 7, grp = lane >> 3;
     const int wave = first_lane((int)(threadIdx.x >> 6));
-    R *acts_lds = rowsT + 8 * kWave + (size_t)wave * 6 * NL * kWave;
     const int set = blockIdx.y;
     const int T = a.T;
     const int per_set = a.B / a.n_sets;
     const TableauData &tab = kTableau[method];
     const int S = tab.S;
+    constexpr int kSlot = (NL + 1) * kWave;
 
-    MlpRegs<R, NL> W;
-    mlp_load<R, NL>(W, a.nn_p + (size_t)set * a.P, a.H, lane);
+    const R *__restrict__ nn_set = a.nn_p + (size_t)set * a.P;
+    using ES = EdgeSlots<NL>;
+    using Edge = std::conditional_t<kEdgeLds<R>, EdgeLds<R, NL>, EdgeRegs<R, NL>>;
+    Edge E;
+    if constexpr (kEdgeLds<R>) {
+        R *edgeW = rowsT + 8 * kWave;
+        R *edgeG = edgeW + ES::count * kWave + (size_t)wave * ES::count * kWave;
+        edge_table_store<R, NL>(edgeW, nn_set, a.H, threadIdx.x, 64 * kBwdWaves);
+        for (int i = lane; i < ES::count * kWave; i += kWave) edgeG[i] = R(0);
+        E.w = edgeW; E.gacc = edgeG; E.lane = lane;
+    } else {
+        const R livej = (lane < a.H) ? R(1) : R(0);
+        const int j = (lane < a.H) ? lane : a.H - 1;
+        const R *pout = nn_set + 9 * a.H + a.H + (size_t)(NL - 1) * ((size_t)a.H * a.H + a.H);
+#pragma unroll
+        for (int i = 0; i < ES::count; ++i) { E.w[i] = R(0); E.gacc[i] = R(0); }
+#pragma unroll
+        for (int i = 0; i < 9; ++i) E.w[ES::w1 + i] = livej * nn_set[j * 9 + i];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) E.w[ES::w5 + q] = livej * pout[q * a.H + j];
+    }
     OdeP<R> o;
     ode_load(o, a.ode_p + 17 * set);
-    if (wave == 0) wt_store<R, NL>(wt, W, lane);
-    tableau_rows_store<R>(rows, method, threadIdx.x, 256);
-    tableau_rowsT_store<R>(rowsT, method, threadIdx.x, 256);
+    wt_rot_store<R>(wt, nn_set, a.H, NL - 1, threadIdx.x, 64 * kBwdWaves);
+    tableau_rowsT_store<R>(rowsT, method, threadIdx.x, 64 * kBwdWaves);
     __syncthreads();
 
-    MlpGrads<R, NL> g;
-    grads_zero(g);
+    R gwh[(NL > 1) ? NL - 1 : 1][kMaxH];
+#pragma unroll
+    for (int l = 0; l < ((NL > 1) ? NL - 1 : 1); ++l)
+#pragma unroll
+        for (int k = 0; k < kMaxH; ++k) gwh[l][k] = R(0);
     R go[17];
 #pragma unroll
     for (int i = 0; i < 17; ++i) go[i] = R(0);
     const bool use_gd = a.gd_mode != 0;
 
-    for (int bi = blockIdx.x * 4 + wave; bi < per_set; bi += gridDim.x * 4) {
+    for (int bi = blockIdx.x * kBwdWaves + wave; bi < per_set; bi += gridDim.x * kBwdWaves) {
         const int b = set * per_set + bi;
         const R *__restrict__ tg = a.t + (a.t_batched ? (size_t)b * T : 0);
         const R *__restrict__ tape = a.tape + (size_t)b * a.max_steps * 8;
         const int *__restrict__ tseg = a.tape_seg + (size_t)b * a.max_steps;
+        const R *__restrict__ stg = a.tape_stage + (size_t)b * a.max_steps * 6 * kSlot;
         const R *__restrict__ gyb = a.gy + (size_t)b * T * 6;
         const int n = a.nsteps[b];
         const bool ok = a.status[b] == HODE_ST_OK;
@@ -89,51 +122,55 @@ __global__ __launch_bounds__(256, 1) void solve_bwd_kernel(const AdjArgs<R> a, c
             for (int r = k + 1; r <= hi; ++r) lam += (c8 < 6) ? gyb[(size_t)r * 6 + c8] : R(0);
             knext = k;
             const R tc = tape[(size_t)st * 8 + 0], h = tape[(size_t)st * 8 + 1];
-            const R Y0 = (c8 < 6) ? tape[(size_t)st * 8 + 2 + c8] : R(0);
             const R t0 = tg[k], t1 = tg[k + 1];
-            const R m0 = inp_at_b(a.meal, a.meal_mode, b, T, k), m1 = inp_at_b(a.meal, a.meal_mode, b, T, k + 1);
             const R v0 = inp_at_b(a.tvns, a.tvns_mode, b, T, k), v1 = inp_at_b(a.tvns, a.tvns_mode, b, T, k + 1);
             const R d0 = inp_at_b(a.gd, a.gd_mode, b, T, k), d1 = inp_at_b(a.gd, a.gd_mode, b, T, k + 1);
             const R inv_len = first_lane(R(1) / (t1 - t0));
-            const R dm = first_lane(m1 - m0), dv = first_lane(v1 - v0), dd = first_lane(d1 - d0);
+            const R dv = first_lane(v1 - v0), dd = first_lane(d1 - d0);
 
-            // ---- pass 1: recompute the stages, keep the derivatives packed and the activations in LDS
-            R KK = R(0);
-#pragma unroll 1
-            for (int s = 0; s < S; ++s) {
-                const R Ys = rfma(h, group_sum8(rows[s * kWave + lane] * KK), Y0);
-                const R ts = rfma((R)tab.c[s], h, tc);
-                const R al = (ts - t0) * inv_len;
-                const R gde = use_gd ? gd_effect(o, rfma(al, dd, d0)) : R(0);
-                MlpActs<R, NL> ac;
-                const R F = rhs_eval<R, NL, true>(W, o, ts, Ys, rfma(al, dm, m0), rfma(al, dv, v0), gde, lane, &ac);
-                KK = (grp == s) ? F : KK;
+            // reverse sweep over the stages.  kb_s = h (b_s lam + sum_{j>s} a_js Z_j),  Z_s = J_s^T kb_s
+            const R *__restrict__ slot = stg + ((size_t)st * 6 + (S - 1)) * kSlot + lane;
+            MlpActs<R, NL> ac;
+            R Ys;
 #pragma unroll
-                for (int l = 0; l < NL; ++l) acts_lds[((size_t)s * NL + l) * kWave + lane] = ac.h[l];
-            }
-            // ---- pass 2: reverse sweep.  kb_s = h (b_s lam + sum_{j>s} a_js Z_j),  Z_s = J_s^T kb_s
+            for (int l = 0; l < NL; ++l) ac.h[l] = slot[l * kWave];
+            Ys = slot[NL * kWave];
             R ZZ = R(0);
 #pragma unroll 1
             for (int s = S - 1; s >= 0; --s) {
-                const R Ys = rfma(h, group_sum8(rows[s * kWave + lane] * KK), Y0);
+                // prefetch the next (earlier) stage's record while this one is processed
+                MlpActs<R, NL> acn;
+                R Ysn = R(0);
+                if (s > 0) {
+                    const R *__restrict__ sn = slot - kSlot;
+#pragma unroll
+                    for (int l = 0; l < NL; ++l) acn.h[l] = sn[l * kWave];
+                    Ysn = sn[NL * kWave];
+                } else {
+#pragma unroll
+                    for (int l = 0; l < NL; ++l) acn.h[l] = R(0);
+                }
                 const R kb = h * rfma((R)tab.bw[s], lam, group_sum8(rowsT[s * kWave + lane] * ZZ));
                 const R ts = rfma((R)tab.c[s], h, tc);
                 const R al = (ts - t0) * inv_len;
                 const R gdv = rfma(al, dd, d0);
                 const R gde = use_gd ? gd_effect(o, gdv) : R(0);
-                MlpActs<R, NL> ac;
-#pragma unroll
-                for (int l = 0; l < NL; ++l) ac.h[l] = acts_lds[((size_t)s * NL + l) * kWave + lane];
-                const R Z = rhs_vjp<R, NL, GODE, false>(W, wt, o, ts, Ys, rfma(al, dm, m0), rfma(al, dv, v0), gde, gdv,
-                                                        use_gd, lane, ac, kb, g, go, nullptr);
+                const R Z = rhs_vjp<R, NL, GODE, false>(E, gwh, wt, o, ts, Ys, rfma(al, dv, v0), gde, gdv, use_gd, lane, ac, kb,
+                                                        go, nullptr);
                 ZZ = (grp == s) ? Z : ZZ;
+                ac = acn;
+                Ys = Ysn;
+                slot -= kSlot;
             }
             lam += group_sum8(rowsT[7 * kWave + lane] * ZZ);
         }
         if (lane < 6) a.gx0[(size_t)b * 6 + lane] = lam + gyb[lane];
     }
 
-    if (a.gnn) grads_flush<R, NL>(g, a.gnn + (size_t)set * a.P, a.H, lane);
+    if (a.gnn) {
+        hidden_flush<R, NL>(gwh, a.gnn + (size_t)set * a.P, a.H, lane);
+        edge_flush<R, NL>(E, a.gnn + (size_t)set * a.P, a.H, lane);
+    }
     if constexpr (GODE) {
         if (a.gode && lane == 0) {
 #pragma unroll
@@ -145,12 +182,12 @@ __global__ __launch_bounds__(256, 1) void solve_bwd_kernel(const AdjArgs<R> a, c
 template <typename R, int NL> static int launch_bwd_nl(hipStream_t s, const AdjArgs<R> &a, int method)
 {
     const int per_set = a.B / a.n_sets;
-    int blocks = (per_set + 3) / 4;
-    if (blocks > 256) blocks = 256;             // one 4-wave workgroup per CU, waves loop over trajectories
+    int blocks = (per_set + kBwdWaves - 1) / kBwdWaves;
+    if (blocks > 256) blocks = 256;             // one 8-wave workgroup per CU, waves loop over trajectories
     if (a.n_sets > 1 && blocks * a.n_sets > 256) blocks = (256 + a.n_sets - 1) / a.n_sets;
     if (blocks < 1) blocks = 1;
     const size_t lds = bwd_lds_elems<R, NL>() * sizeof(R);
-    dim3 grid(blocks, a.n_sets), block(256);
+    dim3 grid(blocks, a.n_sets), block(64 * kBwdWaves);
     if (a.gode) {
         auto kern = solve_bwd_kernel<R, NL, true>;
         if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
@@ -192,10 +229,21 @@ __global__ __launch_bounds__(256, 1) void rhs_bwd_kernel(const RhsArgs<R> a)
     mlp_load<R, NL>(W, a.nn_p, a.H, lane);
     OdeP<R> o;
     ode_load(o, a.ode_p);
-    if (wave == 0) wt_store<R, NL>(wt, W, lane);
+    wt_rot_store<R>(wt, a.nn_p, a.H, NL - 1, threadIdx.x, 256);
     __syncthreads();
-    MlpGrads<R, NL> g;
-    grads_zero(g);
+    using ES = EdgeSlots<NL>;
+    EdgeRegs<R, NL> E;
+#pragma unroll
+    for (int i = 0; i < ES::count; ++i) { E.w[i] = R(0); E.gacc[i] = R(0); }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) E.w[ES::w1 + i] = W.w1[i];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) E.w[ES::w5 + q] = W.w5[q];
+    R gwh[(NL > 1) ? NL - 1 : 1][kMaxH];
+#pragma unroll
+    for (int l = 0; l < ((NL > 1) ? NL - 1 : 1); ++l)
+#pragma unroll
+        for (int k = 0; k < kMaxH; ++k) gwh[l][k] = R(0);
     R go[17];
 #pragma unroll
     for (int i = 0; i < 17; ++i) go[i] = R(0);
@@ -210,12 +258,14 @@ __global__ __launch_bounds__(256, 1) void rhs_bwd_kernel(const RhsArgs<R> a)
         MlpActs<R, NL> ac;
         (void)rhs_eval<R, NL, true>(W, o, t, Y, meal, tvns, gde, lane, &ac);
         R gt;
-        const R Z = rhs_vjp<R, NL, GODE, true>(W, wt, o, t, Y, meal, tvns, gde, gdv, a.gd != nullptr, lane, ac, kb, g,
-                                               go, &gt);
+        const R Z = rhs_vjp<R, NL, GODE, true>(E, gwh, wt, o, t, Y, tvns, gde, gdv, a.gd != nullptr, lane, ac, kb, go, &gt);
         if (lane < 6) a.gx[(size_t)s * 6 + lane] = Z;
         if (a.gt && lane == 0) a.gt[s] = gt;
     }
-    if (a.gnn) grads_flush<R, NL>(g, a.gnn, a.H, lane);
+    if (a.gnn) {
+        hidden_flush<R, NL>(gwh, a.gnn, a.H, lane);
+        edge_flush<R, NL>(E, a.gnn, a.H, lane);
+    }
     if constexpr (GODE) {
         if (a.gode && lane == 0) {
 #pragma unroll

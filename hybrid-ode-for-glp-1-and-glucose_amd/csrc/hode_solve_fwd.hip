@@ -21,7 +21,7 @@ template <typename R> struct Eps;
 template <> struct Eps<float> { static constexpr float v = 1.1920929e-7f; };
 template <> struct Eps<double> { static constexpr double v = 2.220446049250313e-16; };
 
-template <typename R, int NL, int METHOD, int LB>
+template <typename R, int NL, int METHOD, int LB, bool TAPE>
 __global__ __launch_bounds__(64, LB) void solve_fwd_kernel(const SolveArgs<R> a)
 {
     __shared__ R rows[8 * kWave];             // tableau coefficient rows (hode_device.h)
@@ -40,8 +40,11 @@ __global__ __launch_bounds__(64, LB) void solve_fwd_kernel(const SolveArgs<R> a)
 
     const R *__restrict__ tg = a.t + (a.t_batched ? (size_t)b * T : 0);
     R *__restrict__ yb = a.y + (size_t)b * T * 6;
-    R *__restrict__ tape = a.tape ? a.tape + (size_t)b * a.max_steps * 8 : nullptr;
-    int *__restrict__ tseg = a.tape ? a.tape_seg + (size_t)b * a.max_steps : nullptr;
+    R *__restrict__ tape = TAPE ? a.tape + (size_t)b * a.max_steps * 8 : nullptr;
+    int *__restrict__ tseg = TAPE ? a.tape_seg + (size_t)b * a.max_steps : nullptr;
+    // stage tape: [step][stage 0..5][NL activations + stage state][64 lanes]
+    constexpr int kSlot = (NL + 1) * kWave;
+    R *__restrict__ stg = TAPE ? a.tape_stage + (size_t)b * a.max_steps * 6 * kSlot : nullptr;
     const bool use_gd = a.gd_mode != 0;
     const TableauData &tab = kTableau[METHOD];
 
@@ -67,13 +70,26 @@ __global__ __launch_bounds__(64, LB) void solve_fwd_kernel(const SolveArgs<R> a)
         const R inv_len = first_lane(R(1) / len);
         const R dm = first_lane(m1 - m0), dv = first_lane(v1 - v0), dd = first_lane(d1 - d0);
         // piecewise-linear forcing on this interval (models/hybrid_ode_nn.py:217-229)
-        auto f_at = [&](R ts, R Ys) -> R {
+        // slot >= 0 (TAPE): also record the layer activations and the stage state for the adjoint
+        auto f_at = [&](R ts, R Ys, int slot) -> R {
             const R al = (ts - t0) * inv_len;
             const R gde = use_gd ? gd_effect(o, rfma(al, dd, d0)) : R(0);
-            return rhs_eval<R, NL, false>(W, o, ts, Ys, rfma(al, dm, m0), rfma(al, dv, v0), gde, lane, nullptr);
+            if constexpr (TAPE) {
+                MlpActs<R, NL> ac;
+                const R F = rhs_eval<R, NL, true>(W, o, ts, Ys, rfma(al, dm, m0), rfma(al, dv, v0), gde, lane, &ac);
+                if (slot >= 0 && slot < a.max_steps * 6) {
+                    R *dst = stg + (size_t)slot * kSlot + lane;
+#pragma unroll
+                    for (int l = 0; l < NL; ++l) dst[l * kWave] = ac.h[l];
+                    dst[NL * kWave] = Ys;
+                }
+                return F;
+            } else {
+                return rhs_eval<R, NL, false>(W, o, ts, Ys, rfma(al, dm, m0), rfma(al, dv, v0), gde, lane, nullptr);
+            }
         };
         auto tape_put = [&](R tc, R h) {
-            if (tape) {
+            if constexpr (TAPE) {
                 // entry = {t, h, y0..y5}: lanes 0..5 store the state, lanes 6,7 store t and h
                 const R e = (lane < 6) ? Y : (lane == 6) ? tc : h;
                 if (lane < 8) tape[(size_t)ns * 8 + ((lane < 6) ? lane + 2 : lane - 6)] = e;
@@ -88,7 +104,7 @@ __global__ __launch_bounds__(64, LB) void solve_fwd_kernel(const SolveArgs<R> a)
 #pragma unroll 1
             for (int s = 0; s < 4; ++s) {
                 const R Ys = rfma(hh, group_sum8(rows[s * kWave + lane] * KK), Y);
-                const R F = f_at(rfma((R)tab.c[s], hh, t0), Ys);
+                const R F = f_at(rfma((R)tab.c[s], hh, t0), Ys, ns * 6 + s);
                 KK = (grp == s) ? F : KK;
             }
             if (ns < a.max_steps) tape_put(t0, hh);
@@ -98,14 +114,14 @@ __global__ __launch_bounds__(64, LB) void solve_fwd_kernel(const SolveArgs<R> a)
         } else {
             if (!have_f) {
                 // first derivative + Hairer's initial step (scipy/integrate/_ivp/common.py:68-135)
-                const R K1 = f_at(t0, Y);
+                const R K1 = f_at(t0, Y, 0);
                 const R sc = (c8 < 6) ? (a.atol + rabs(Y) * a.rtol) : R(1);
                 const R q0 = Y / sc, q1 = K1 / sc;
                 const float dn0 = sqrtf((float)first_lane(oct_allsum(q0 * q0)) / 6.0f);
                 const float dn1 = sqrtf((float)first_lane(oct_allsum(q1 * q1)) / 6.0f);
                 float h0 = (dn0 < 1e-5f || dn1 < 1e-5f) ? 1e-6f : 0.01f * dn0 / dn1;
                 h0 = fminf(h0, (float)len);
-                const R f1 = f_at(t0 + (R)h0, rfma((R)h0, K1, Y));
+                const R f1 = f_at(t0 + (R)h0, rfma((R)h0, K1, Y), -1);
                 const R q2 = (f1 - K1) / sc;
                 const float dn2 = sqrtf((float)first_lane(oct_allsum(q2 * q2)) / 6.0f) / h0;
                 const float h1 = (dn1 <= 1e-15f && dn2 <= 1e-15f) ? fmaxf(1e-6f, h0 * 1e-3f)
@@ -132,7 +148,8 @@ __global__ __launch_bounds__(64, LB) void solve_fwd_kernel(const SolveArgs<R> a)
                     for (int s = 1; s <= 6; ++s) {        // stages 2..6 and the FSAL stage (row 6 = 5th-order weights)
                         Ys = rfma(h, group_sum8(rows[s * kWave + lane] * KK), Y);
                         const R ts = (s >= 5) ? tn : rfma((R)tab.c[s], h, tc);
-                        F = f_at(ts, Ys);
+                        // stage s of this step; the FSAL stage (s == 6) is stage 0 of the NEXT step
+                        F = f_at(ts, Ys, (s < 6) ? ns * 6 + s : (ns + 1) * 6);
                         KK = (grp == s) ? F : KK;
                     }
                     const R Yn = Ys;                      // 5th-order solution
@@ -185,10 +202,14 @@ template <typename R, int NL>
 static int launch_nl(hipStream_t s, const SolveArgs<R> &a, int method)
 {
     dim3 grid(a.B), block(64);
-    if (method == HODE_METHOD_DP54)
-        hipLaunchKernelGGL((solve_fwd_kernel<R, NL, HODE_METHOD_DP54, (sizeof(R) == 4 ? 2 : 1)>), grid, block, 0, s, a);
-    else
-        hipLaunchKernelGGL((solve_fwd_kernel<R, NL, HODE_METHOD_RK4, (sizeof(R) == 4 ? 2 : 1)>), grid, block, 0, s, a);
+    constexpr int LB = (sizeof(R) == 4 ? 2 : 1);
+    if (method == HODE_METHOD_DP54) {
+        if (a.tape) hipLaunchKernelGGL((solve_fwd_kernel<R, NL, HODE_METHOD_DP54, LB, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((solve_fwd_kernel<R, NL, HODE_METHOD_DP54, LB, false>), grid, block, 0, s, a);
+    } else {
+        if (a.tape) hipLaunchKernelGGL((solve_fwd_kernel<R, NL, HODE_METHOD_RK4, LB, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((solve_fwd_kernel<R, NL, HODE_METHOD_RK4, LB, false>), grid, block, 0, s, a);
+    }
     return hipGetLastError() == hipSuccess ? HODE_OK : HODE_ELAUNCH;
 }
 

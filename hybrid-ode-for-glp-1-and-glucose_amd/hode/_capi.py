@@ -41,7 +41,7 @@ def load():
         _lib = C.CDLL(_SO)
         _lib.hode_version.restype = C.c_char_p
         _lib.hode_tape_bytes.restype = C.c_size_t
-        _lib.hode_tape_bytes.argtypes = [C.c_int, C.c_int, C.c_int]
+        _lib.hode_tape_bytes.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
     return _lib
 
 
@@ -138,7 +138,14 @@ def solve_fwd(x0, t, meal, tvns, gd, ode_p, nn_p, H, L, method=METHOD_DP54, rtol
     if nn_p.numel() != n_sets * n_params(H, L) or ode_p.numel() != 17 * n_sets:
         raise HodeError("parameter vector size does not match (H, L, n_sets)")
     if max_steps is None:
-        max_steps = (T - 1) if method == METHOD_RK4 else 8 * (T - 1) + 64
+        # accepted-step budget per trajectory.  With a tape every step costs 6*(L+1)*256 B of HBM (stage
+        # tape), so the default is tighter there; a trajectory that needs more reports status 1.
+        if method == METHOD_RK4:
+            max_steps = max(T - 1, 1)
+        elif want_tape:
+            max_steps = (T - 1) + max(32, (T - 1) // 4)
+        else:
+            max_steps = 8 * (T - 1) + 64
     s = Solve()
     s.y = torch.empty(B, T, 6, dtype=dt, device=dev)
     s.status = torch.empty(B, dtype=torch.int32, device=dev)
@@ -147,7 +154,7 @@ def solve_fwd(x0, t, meal, tvns, gd, ode_p, nn_p, H, L, method=METHOD_DP54, rtol
     s.max_steps = max_steps
     s.tape = None
     if want_tape:
-        nbytes = load().hode_tape_bytes(B, max_steps, x0.element_size())
+        nbytes = load().hode_tape_bytes(B, max_steps, x0.element_size(), L)
         s.tape = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     fn = getattr(load(), f"hode_solve_fwd_{_sfx(dt)}")
     rc = fn(_stream(), C.c_int(B), C.c_int(T), _ptr(x0), _ptr(t), C.c_int(t_batched),

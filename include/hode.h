@@ -58,8 +58,12 @@ const char *hode_version(void);
 /* number of MLP parameters for (H hidden, L hidden layers); 13510 for (64,4) */
 int hode_nn_param_count(int H, int L);
 
-/* bytes of one tape entry / of the whole tape the solve writes for the adjoint */
-size_t hode_tape_bytes(int B, int max_steps, int elem_size /* 4 or 8 */);
+/* bytes of the tape the solve writes for the adjoint: per accepted step {t, h, y[6]}, the grid
+ * interval, and the "stage tape" -- the MLP activations and stage state of every Runge-Kutta stage
+ * (6 x (L+1) x 64 reals per step), so that the adjoint never recomputes the forward.  This is a
+ * memory-for-compute trade sized for 288 GB of HBM: 7.7 KB per step in fp32 for L = 4, i.e.
+ * 2.3 MB per trajectory at max_steps = 300. */
+size_t hode_tape_bytes(int B, int max_steps, int elem_size /* 4 or 8 */, int L);
 
 /* ---- K1: RHS forward.  Replaces HybridODENN.ode_residual (models/hybrid_ode_nn.py:108-134)
  *      = ODECore.forward (models/ode_core.py:81-166) + NNResidual.forward
@@ -86,8 +90,8 @@ int hode_rhs_bwd_f64(void *stream, int B, const double *x, const double *t, cons
  *      (:210-231) and the RK45 stepper (scipy/integrate/_ivp/rk.py:14-72,111-176).
  *      t: [T] (t_batched=0) or [B,T] (t_batched=1).  y[B,T,6] written (rows after a failure
  *      are zero).  status/nsteps/nfev: int32[B] (nsteps/nfev may be NULL).
- *      tape: NULL, or hode_tape_bytes(B,max_steps,sizeof(real)) bytes that receive the accepted
- *      steps (needed by hode_solve_bwd_*).                                                      */
+ *      tape: NULL, or hode_tape_bytes(B,max_steps,sizeof(real),L) bytes (256-byte aligned) that
+ *      receive the accepted steps and their stage activations (needed by hode_solve_bwd_*).     */
 int hode_solve_fwd_f32(void *stream, int B, int T, const float *x0, const float *t, int t_batched,
                        const float *meal, int meal_mode, const float *tvns, int tvns_mode,
                        const float *gd, int gd_mode, const float *ode_p, const float *nn_p,

@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     assert hode.version().startswith("hode ")
     assert lib.hode_nn_param_count(64, 4) == 13510 and lib.hode_nn_param_count(32, 2) == 1574
-    assert hode.load().hode_tape_bytes(4096, 1984, 4) == 4096 * 1984 * 36
+    assert hode.load().hode_tape_bytes(4096, 300, 4, 4) == 4096 * 300 * 36 + 4096 * 300 * 6 * 5 * 64 * 4
 
 
 def test_argument_validation_without_gpu():

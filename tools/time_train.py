@@ -1,0 +1,23 @@
+"""Per-kernel timing of the training step (development aid)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "hybrid-ode-for-glp-1-and-glucose_amd")); sys.path.insert(0, ROOT)
+import torch, hode, bench
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+dev = torch.device("cuda")
+x0, t, meal, tv = (v.to(dev) for v in bench.synth_cohort(B, 1000))
+nn = bench.synth_weights(0).to(dev); ode = bench.ODE_DEFAULT.to(dev)
+obs = hode.solve_fwd(x0, t, meal, tv, None, ode, nn, 64, 4).y + 0.1 * torch.randn(B, 241, 6, device=dev)
+def timeit(f, n=5):
+    f(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): r = f()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n, r
+ms_f, _ = timeit(lambda: hode.solve_fwd(x0, t, meal, tv, None, ode, nn, 64, 4))
+ms_ft, sol = timeit(lambda: hode.solve_fwd(x0, t, meal, tv, None, ode, nn, 64, 4, want_tape=True))
+ms_m, (ls, gy) = timeit(lambda: hode.mse_fwd_bwd(sol.y, obs, 1.0 / sol.y.numel()))
+ms_b, _ = timeit(lambda: hode.solve_bwd(sol, gy))
+ms_bo, _ = timeit(lambda: hode.solve_bwd(sol, gy, want_gode=True))
+print(f"B={B}: fwd {ms_f:.2f} ms | fwd+tape {ms_ft:.2f} ms (tape {sol.tape.numel()/2**30:.2f} GiB) | mse {ms_m:.3f} ms | bwd {ms_b:.2f} ms | bwd+gode {ms_bo:.2f} ms")
