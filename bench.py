@@ -168,7 +168,7 @@ def main():
         n_glob = world * B * T * 6
 
         def compute(p):
-            ls, gnn, gode, _ = hode.train.hip_loss_and_grads(p, ode, x0, t, meal, tvns, obs, H, L, n_glob)
+            ls, gnn, gode, _ = hode.train.hip_loss_and_grads(p, ode, x0, t, meal, tvns, obs, H, L, n_glob, state=state)
             return ls, gnn, gode, B * T * 6
 
         losses = [float(hode.train.train_step(state, compute)) for _ in range(2)]       # warm-up

@@ -122,8 +122,15 @@ class Solve:
     __slots__ = ("y", "status", "nsteps", "nfev", "tape", "max_steps", "ctx")
 
 
+def tape_nbytes(B, max_steps, elem_size, L):
+    return load().hode_tape_bytes(B, max_steps, elem_size, L)
+
+
 def solve_fwd(x0, t, meal, tvns, gd, ode_p, nn_p, H, L, method=METHOD_DP54, rtol=1e-6, atol=1e-8,
-              max_steps=None, n_sets=1, want_tape=False):
+              max_steps=None, n_sets=1, want_tape=False, tape=None):
+    """Forward solve.  want_tape=True records what the adjoint needs; pass `tape=` (a uint8 tensor of at least
+    tape_nbytes(...) bytes, e.g. the `.tape` of an earlier solution of the same shape) to reuse the buffer
+    instead of allocating several GB per call."""
     _need_gpu(x0)
     dt, dev = x0.dtype, x0.device
     x0 = x0.contiguous()
@@ -153,9 +160,14 @@ def solve_fwd(x0, t, meal, tvns, gd, ode_p, nn_p, H, L, method=METHOD_DP54, rtol
     s.nfev = torch.empty(B, dtype=torch.int32, device=dev)
     s.max_steps = max_steps
     s.tape = None
-    if want_tape:
+    if want_tape or tape is not None:
         nbytes = load().hode_tape_bytes(B, max_steps, x0.element_size(), L)
-        s.tape = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        if tape is not None:
+            if tape.dtype != torch.uint8 or not tape.is_cuda or tape.numel() < nbytes or tape.data_ptr() % 256:
+                raise HodeError(f"tape buffer must be a 256-byte aligned uint8 device tensor of >= {nbytes} bytes")
+            s.tape = tape
+        else:
+            s.tape = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     fn = getattr(load(), f"hode_solve_fwd_{_sfx(dt)}")
     rc = fn(_stream(), C.c_int(B), C.c_int(T), _ptr(x0), _ptr(t), C.c_int(t_batched),
             _ptr(meal), C.c_int(_mode(meal, B, T)), _ptr(tvns), C.c_int(_mode(tvns, B, T)),

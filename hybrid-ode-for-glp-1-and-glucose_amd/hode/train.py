@@ -36,6 +36,7 @@ class TrainState:
     v: torch.Tensor = None
     step: int = 0
     scratch: torch.Tensor = field(default=None, repr=False)
+    tape: torch.Tensor = field(default=None, repr=False)      # reused across steps (several GB)
 
     def __post_init__(self):
         if self.m is None:
@@ -61,11 +62,14 @@ def unpack(buf: torch.Tensor, P: int):
 
 
 def hip_loss_and_grads(p, ode_p, x0, t, meal, tvns, obs, H, L, n_elem_global, rtol=1e-6, atol=1e-8,
-                       want_gode=False):
+                       want_gode=False, state: Optional[TrainState] = None):
     """Local shard: forward solve (tape) -> fused MSE + cotangent -> adjoint.  Returns
     (sum of squared errors fp64[1], gnn, gode|None, solve).  The cotangent is scaled by the GLOBAL
     element count so that summing the ranks' gradients gives the gradient of the global mean."""
-    sol = capi.solve_fwd(x0, t, meal, tvns, None, ode_p, p, H, L, rtol=rtol, atol=atol, want_tape=True)
+    sol = capi.solve_fwd(x0, t, meal, tvns, None, ode_p, p, H, L, rtol=rtol, atol=atol, want_tape=True,
+                         tape=None if state is None else state.tape)
+    if state is not None:
+        state.tape = sol.tape
     loss_sum, gy = capi.mse_fwd_bwd(sol.y, obs, 1.0 / float(n_elem_global))
     _, gnn, gode = capi.solve_bwd(sol, gy, want_gnn=True, want_gode=want_gode)
     return loss_sum, gnn, gode, sol

@@ -16,7 +16,8 @@ def timeit(f, n=5):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n, r
 ms_f, _ = timeit(lambda: hode.solve_fwd(x0, t, meal, tv, None, ode, nn, 64, 4))
-ms_ft, sol = timeit(lambda: hode.solve_fwd(x0, t, meal, tv, None, ode, nn, 64, 4, want_tape=True))
+sol = hode.solve_fwd(x0, t, meal, tv, None, ode, nn, 64, 4, want_tape=True)
+ms_ft, sol = timeit(lambda: hode.solve_fwd(x0, t, meal, tv, None, ode, nn, 64, 4, want_tape=True, tape=sol.tape))
 ms_m, (ls, gy) = timeit(lambda: hode.mse_fwd_bwd(sol.y, obs, 1.0 / sol.y.numel()))
 ms_b, _ = timeit(lambda: hode.solve_bwd(sol, gy))
 ms_bo, _ = timeit(lambda: hode.solve_bwd(sol, gy, want_gode=True))
