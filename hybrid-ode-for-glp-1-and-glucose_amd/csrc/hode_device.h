@@ -576,6 +576,118 @@ __device__ __forceinline__ double wt_mul(const double *__restrict__ wt, int lane
     return acc0 + acc1;
 }
 
+// Where the transposed hidden matrices live for the delta propagation:
+//   WtLds  : the LDS image above (2 waves/SIMD fit, every group of 4 reads is an LDS-latency wait)
+//   WtRegs : 64 more registers per hidden matrix in the same rotating-operand order (1 wave/SIMD,
+//            no memory wait inside the 64-FMA loop); fp32 only
+template <typename R> struct WtLds {
+    const R *wt;
+    __device__ __forceinline__ R mul(int l, int lane, R d) const { return wt_mul(wt + (size_t)l * kMaxH * kMaxH, lane, d); }
+};
+template <int N> __device__ __forceinline__ void wt_reg_step(const float (&w)[kMaxH], const float (&Rr)[4], float (&acc)[4])
+{
+    acc[0] = fmac_ror<N>(acc[0], Rr[0], w[0 * 16 + N]);
+    acc[1] = fmac_ror<N>(acc[1], Rr[1], w[1 * 16 + N]);
+    acc[2] = fmac_ror<N>(acc[2], Rr[2], w[2 * 16 + N]);
+    acc[3] = fmac_ror<N>(acc[3], Rr[3], w[3 * 16 + N]);
+    if constexpr (N < 15) wt_reg_step<N + 1>(w, Rr, acc);
+}
+template <int NL> struct WtRegs {
+    float w[(NL > 1) ? NL - 1 : 1][kMaxH];     // w[l][16q+n] on lane k = W_l[16q + ((k - n) & 15)][k]
+    __device__ __forceinline__ void load(const float *__restrict__ nn_p, int H, int lane)
+    {
+        const float *Wl = nn_p + 9 * H + H;
+#pragma unroll
+        for (int l = 0; l < NL - 1; ++l) {
+#pragma unroll
+            for (int r = 0; r < kMaxH; ++r) {
+                const int j = (r & 48) | ((lane - r) & 15);
+                const bool in = (j < H) && (lane < H);
+                w[l][r] = in ? Wl[(size_t)(in ? j : 0) * H + (in ? lane : 0)] : 0.f;
+            }
+            Wl += (size_t)H * H + H;
+        }
+    }
+    __device__ __forceinline__ float mul(int l, int lane, float d) const
+    {
+        (void)lane;
+        float Rr[4];
+        rows_replicate(d, Rr);
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        // l is a compile-time constant at every call site (unrolled layer loop)
+        wt_reg_step<0>(w[l], Rr, acc);
+        return (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    }
+};
+
+// One hidden layer of the backward pass: gw += d (x) hin  and  returns W^T d.
+// Generic form: the two products one after the other.
+template <typename R, typename Wt>
+__device__ __forceinline__ R layer_bwd(R (&gw)[kMaxH], const Wt &wt, int l, int lane, R d, R hin)
+{
+    mlp_outer_acc(gw, d, hin);
+    return wt.mul(l, lane, d);
+}
+// fp32 + LDS-resident transposed matrix: the outer-product FMAs (which need no memory) are interleaved
+// with the W^T product so that each group of four 16-byte LDS reads has 16 independent FMAs between its
+// issue and its first use -- the LDS latency hides behind work of the same wave.
+template <int G>
+__device__ __forceinline__ void layer_bwd_group(float (&gw)[kMaxH], const Vec4<float> *__restrict__ wt4, int lane, float d,
+                                                const float (&Rh)[4], const float (&Rd)[4], float (&acc)[4])
+{
+    const Vec4<float> w0 = wt4[(4 * G + 0) * kMaxH + lane], w1 = wt4[(4 * G + 1) * kMaxH + lane],
+                      w2 = wt4[(4 * G + 2) * kMaxH + lane], w3 = wt4[(4 * G + 3) * kMaxH + lane];
+    constexpr int n = 4 * G;
+    gw[0 * 16 + n + 0] = fmac_ror<n + 0>(gw[0 * 16 + n + 0], Rh[0], d);
+    gw[1 * 16 + n + 0] = fmac_ror<n + 0>(gw[1 * 16 + n + 0], Rh[1], d);
+    gw[2 * 16 + n + 0] = fmac_ror<n + 0>(gw[2 * 16 + n + 0], Rh[2], d);
+    gw[3 * 16 + n + 0] = fmac_ror<n + 0>(gw[3 * 16 + n + 0], Rh[3], d);
+    gw[0 * 16 + n + 1] = fmac_ror<n + 1>(gw[0 * 16 + n + 1], Rh[0], d);
+    gw[1 * 16 + n + 1] = fmac_ror<n + 1>(gw[1 * 16 + n + 1], Rh[1], d);
+    gw[2 * 16 + n + 1] = fmac_ror<n + 1>(gw[2 * 16 + n + 1], Rh[2], d);
+    gw[3 * 16 + n + 1] = fmac_ror<n + 1>(gw[3 * 16 + n + 1], Rh[3], d);
+    gw[0 * 16 + n + 2] = fmac_ror<n + 2>(gw[0 * 16 + n + 2], Rh[0], d);
+    gw[1 * 16 + n + 2] = fmac_ror<n + 2>(gw[1 * 16 + n + 2], Rh[1], d);
+    gw[2 * 16 + n + 2] = fmac_ror<n + 2>(gw[2 * 16 + n + 2], Rh[2], d);
+    gw[3 * 16 + n + 2] = fmac_ror<n + 2>(gw[3 * 16 + n + 2], Rh[3], d);
+    gw[0 * 16 + n + 3] = fmac_ror<n + 3>(gw[0 * 16 + n + 3], Rh[0], d);
+    gw[1 * 16 + n + 3] = fmac_ror<n + 3>(gw[1 * 16 + n + 3], Rh[1], d);
+    gw[2 * 16 + n + 3] = fmac_ror<n + 3>(gw[2 * 16 + n + 3], Rh[2], d);
+    gw[3 * 16 + n + 3] = fmac_ror<n + 3>(gw[3 * 16 + n + 3], Rh[3], d);
+    // rows 4G..4G+3 of the image: r = 16 G + 4 i + c  ->  q = G, n = 4 i + c
+    acc[0] = fmac_ror<0>(acc[0], Rd[G], w0.v[0]);
+    acc[1] = fmac_ror<1>(acc[1], Rd[G], w0.v[1]);
+    acc[2] = fmac_ror<2>(acc[2], Rd[G], w0.v[2]);
+    acc[3] = fmac_ror<3>(acc[3], Rd[G], w0.v[3]);
+    acc[0] = fmac_ror<4>(acc[0], Rd[G], w1.v[0]);
+    acc[1] = fmac_ror<5>(acc[1], Rd[G], w1.v[1]);
+    acc[2] = fmac_ror<6>(acc[2], Rd[G], w1.v[2]);
+    acc[3] = fmac_ror<7>(acc[3], Rd[G], w1.v[3]);
+    acc[0] = fmac_ror<8>(acc[0], Rd[G], w2.v[0]);
+    acc[1] = fmac_ror<9>(acc[1], Rd[G], w2.v[1]);
+    acc[2] = fmac_ror<10>(acc[2], Rd[G], w2.v[2]);
+    acc[3] = fmac_ror<11>(acc[3], Rd[G], w2.v[3]);
+    acc[0] = fmac_ror<12>(acc[0], Rd[G], w3.v[0]);
+    acc[1] = fmac_ror<13>(acc[1], Rd[G], w3.v[1]);
+    acc[2] = fmac_ror<14>(acc[2], Rd[G], w3.v[2]);
+    acc[3] = fmac_ror<15>(acc[3], Rd[G], w3.v[3]);
+    __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ float layer_bwd(float (&gw)[kMaxH], const WtLds<float> &wt, int l, int lane, float d, float hin)
+{
+    const Vec4<float> *wt4 = reinterpret_cast<const Vec4<float> *>(wt.wt + (size_t)l * kMaxH * kMaxH);
+    float Rh[4], Rd[4];
+    rows_replicate(hin, Rh);
+    rows_replicate(d, Rd);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    __builtin_amdgcn_sched_barrier(0);
+    layer_bwd_group<0>(gw, wt4, lane, d, Rh, Rd, acc);
+    layer_bwd_group<1>(gw, wt4, lane, d, Rh, Rd, acc);
+    layer_bwd_group<2>(gw, wt4, lane, d, Rh, Rd, acc);
+    layer_bwd_group<3>(gw, wt4, lane, d, Rh, Rd, acc);
+    return (acc[0] + acc[1]) + (acc[2] + acc[3]);
+}
+
 // ------------------------------------------------------------------------------------------
 // First/last-layer weights and their gradient accumulators ("edge" parameters: W1[.,9], b_1..b_NL,
 // Wout[6,.], bout) behind a small policy, so that the adjoint kernel can keep them in LDS and spend
@@ -593,6 +705,12 @@ template <typename R, int NL> struct EdgeRegs {
     __device__ __forceinline__ void add(int slot, R v) { gacc[slot] += v; }
     __device__ __forceinline__ void fma(int slot, R a, R b) { gacc[slot] = rfma(a, b, gacc[slot]); }
     __device__ __forceinline__ R G(int slot) const { return gacc[slot]; }
+    // gacc[slot] += v[slot] for all slots
+    __device__ __forceinline__ void add_all(const R (&v)[EdgeSlots<NL>::count])
+    {
+#pragma unroll
+        for (int i = 0; i < EdgeSlots<NL>::count; ++i) gacc[i] += v[i];
+    }
 };
 template <typename R, int NL> struct EdgeLds {
     const R *w;      // [slots][64] shared by the workgroup
@@ -604,6 +722,15 @@ template <typename R, int NL> struct EdgeLds {
     __device__ __forceinline__ void add(int slot, R v) { gacc[slot * kWave + lane] += v; }
     __device__ __forceinline__ void fma(int slot, R a, R b) { gacc[slot * kWave + lane] = rfma(a, b, gacc[slot * kWave + lane]); }
     __device__ __forceinline__ R G(int slot) const { return gacc[slot * kWave + lane]; }
+    // all reads first (one LDS wait instead of one per slot), then the adds, then all writes
+    __device__ __forceinline__ void add_all(const R (&v)[EdgeSlots<NL>::count])
+    {
+        R cur[EdgeSlots<NL>::count];
+#pragma unroll
+        for (int i = 0; i < EdgeSlots<NL>::count; ++i) cur[i] = gacc[i * kWave + lane];
+#pragma unroll
+        for (int i = 0; i < EdgeSlots<NL>::count; ++i) gacc[i * kWave + lane] = cur[i] + v[i];
+    }
 };
 // edge weights of one parameter set into a [slots][64] table (weights only; accumulators start at 0)
 template <typename R, int NL>
@@ -668,8 +795,8 @@ __device__ __forceinline__ void hidden_flush(const R (&wh)[(NL > 1) ? NL - 1 : 1
 // same layout and accumulates parameter gradients.  acts = activations of this evaluation (from
 // rhs_eval<KEEP> or from the stage tape).  Needs only the first/last layer weights in registers;
 // the hidden matrices come transposed from LDS (wt).   go[17] (GODE): d/d(ode constants), wave-uniform.
-template <typename R, int NL, bool GODE, bool GT, typename Edge>
-__device__ __forceinline__ R rhs_vjp(Edge &e, R (&gwh)[(NL > 1) ? NL - 1 : 1][kMaxH], const R *__restrict__ wt,
+template <typename R, int NL, bool GODE, bool GT, typename Edge, typename Wt>
+__device__ __forceinline__ R rhs_vjp(Edge &e, R (&gwh)[(NL > 1) ? NL - 1 : 1][kMaxH], const Wt &wt,
                                      const OdeP<R> &o, R t, R Y, R tvns, R gde, R gd_in, bool use_gd, int lane,
                                      const MlpActs<R, NL> &acts, R kb, R (&go)[17], R *gt_out)
 {
@@ -723,32 +850,34 @@ __device__ __forceinline__ R rhs_vjp(Edge &e, R (&gwh)[(NL > 1) ? NL - 1 : 1][kM
     d = rfma(w53, lGLP, d);
     d = rfma(w54, lGE, d);
     d = rfma(w55, lF, d);
-    e.add(S::b5, kb);                            // lane o < 6 holds d bout[o] (other groups hold copies)
-    e.fma(S::w5 + 0, lG, hl);
-    e.fma(S::w5 + 1, lI, hl);
-    e.fma(S::w5 + 2, lGlu, hl);
-    e.fma(S::w5 + 3, lGLP, hl);
-    e.fma(S::w5 + 4, lGE, hl);
-    e.fma(S::w5 + 5, lF, hl);
+    // increments of the edge-parameter gradients are collected and applied in ONE batch at the end
+    R inc[S::count];
+    inc[S::b5] = kb;                             // lane o < 6 holds d bout[o] (other groups hold copies)
+    inc[S::w5 + 0] = lG * hl;
+    inc[S::w5 + 1] = lI * hl;
+    inc[S::w5 + 2] = lGlu * hl;
+    inc[S::w5 + 3] = lGLP * hl;
+    inc[S::w5 + 4] = lGE * hl;
+    inc[S::w5 + 5] = lF * hl;
     d = (hl > R(0)) ? d : R(0);
 #pragma unroll
     for (int l = NL - 1; l >= 1; --l) {           // hidden matrix l-1 maps acts.h[l-1] -> acts.h[l]
         const R hin = acts.h[l - 1];
-        e.add(S::b + l, d);
-        mlp_outer_acc(gwh[l - 1], d, hin);           // dW_l[j][:] += delta_j * h_{l-1}[:]
-        const R dp = wt_mul(wt + (size_t)(l - 1) * kMaxH * kMaxH, lane, d);
+        inc[S::b + l] = d;
+        const R dp = layer_bwd(gwh[l - 1], wt, l - 1, lane, d, hin);   // dW_l += d (x) h_{l-1};  dp = W_l^T d
         d = (hin > R(0)) ? dp : R(0);
     }
-    e.add(S::b + 0, d);
-    e.fma(S::w1 + 0, d, t);
-    e.fma(S::w1 + 1, d, G);
-    e.fma(S::w1 + 2, d, I);
-    e.fma(S::w1 + 3, d, Glu);
-    e.fma(S::w1 + 4, d, GLP1);
-    e.fma(S::w1 + 5, d, GE);
-    e.fma(S::w1 + 6, d, FFA);
-    e.fma(S::w1 + 7, d, GLP1);
-    e.fma(S::w1 + 8, d, tvns);
+    inc[S::b + 0] = d;
+    inc[S::w1 + 0] = d * t;
+    inc[S::w1 + 1] = d * G;
+    inc[S::w1 + 2] = d * I;
+    inc[S::w1 + 3] = d * Glu;
+    inc[S::w1 + 4] = d * GLP1;
+    inc[S::w1 + 5] = d * GE;
+    inc[S::w1 + 6] = d * FFA;
+    inc[S::w1 + 7] = d * GLP1;
+    inc[S::w1 + 8] = d * tvns;
+    e.add_all(inc);
     const R w11 = e.W(S::w1 + 1), w12 = e.W(S::w1 + 2), w13 = e.W(S::w1 + 3), w14 = e.W(S::w1 + 4), w15 = e.W(S::w1 + 5),
             w16 = e.W(S::w1 + 6), w17 = e.W(S::w1 + 7);
     R p[6];

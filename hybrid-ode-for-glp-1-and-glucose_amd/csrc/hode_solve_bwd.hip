@@ -23,6 +23,7 @@
 #include "hode_device.h"
 #include "hode_kernels.h"
 #include <type_traits>
+#include <cstdlib>
 
 namespace hode {
 
@@ -37,20 +38,26 @@ template <typename R> __device__ __forceinline__ R inp_at_b(const R *__restrict_
 //   rowsT [8][64]           transposed tableau rows A[lane>>3][s]; row 7 = 1 for the solution stages
 constexpr int kBwdWaves = 8;
 //   edgeW [16+NL][64]       first/last layer weights (fp32 build; shared)
-//   edgeG [waves][16+NL][64] first/last layer gradient accumulators (fp32 build; per wave, ds_add_f32)
+//   edgeG [waves][16+NL][64] first/last layer gradient accumulators (fp32 build; per wave)
+//   rec   [waves][2][NL+1][64] stage records arriving by LDS-DMA (global_load ... lds), double buffered
 template <typename R> constexpr bool kEdgeLds = (sizeof(R) == 4);
 template <typename R, int NL> __host__ __device__ constexpr size_t bwd_lds_elems()
 {
     return (size_t)(NL > 1 ? NL - 1 : 1) * kMaxH * kMaxH + 8 * kWave +
-           (kEdgeLds<R> ? (size_t)(1 + kBwdWaves) * EdgeSlots<NL>::count * kWave : 0);
+           (kEdgeLds<R> ? (size_t)(1 + kBwdWaves) * EdgeSlots<NL>::count * kWave : 0) +
+           (size_t)kBwdWaves * 2 * (NL + 1) * kWave;      // rec: [waves][2][NL+1][64] stage-record double buffer
 }
 
 // The adjoint reads, for every stage of every accepted step, what the forward recorded on the stage
 // tape (layer activations + stage state): it never recomputes the forward.  Registers therefore hold
 // only the gradient accumulators (211) + the first/last layer weights (15): 2 waves per SIMD in fp32.
-template <typename R, int NL, bool GODE>
-__global__ __launch_bounds__(64 * kBwdWaves, (sizeof(R) == 4 ? 2 : 1)) void solve_bwd_kernel(const AdjArgs<R> a, const int method)
+// WTREG = false: kBwdWaves (8) waves per workgroup, transposed matrices in LDS, 2 waves/SIMD.
+// WTREG = true (fp32): 4 waves per workgroup, transposed matrices in registers, 1 wave/SIMD, no LDS wait
+//         inside the 64-FMA loops.
+template <typename R, int NL, bool GODE, bool WTREG>
+__global__ __launch_bounds__(WTREG ? 256 : 64 * kBwdWaves, (sizeof(R) == 4 && !WTREG ? 2 : 1)) void solve_bwd_kernel(const AdjArgs<R> a, const int method)
 {
+    constexpr int kWaves = WTREG ? 4 : kBwdWaves;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     R *wt = reinterpret_cast<R *>(smem_raw);
     R *rowsT = wt + (size_t)(NL > 1 ? NL - 1 : 1) * kMaxH * kMaxH;
@@ -72,7 +79,7 @@ __global__ __launch_bounds__(64 * kBwdWaves, (sizeof(R) == 4 ? 2 : 1)) void solv
     if constexpr (kEdgeLds<R>) {
         R *edgeW = rowsT + 8 * kWave;
         R *edgeG = edgeW + ES::count * kWave + (size_t)wave * ES::count * kWave;
-        edge_table_store<R, NL>(edgeW, nn_set, a.H, threadIdx.x, 64 * kBwdWaves);
+        edge_table_store<R, NL>(edgeW, nn_set, a.H, threadIdx.x, 64 * kWaves);
         for (int i = lane; i < ES::count * kWave; i += kWave) edgeG[i] = R(0);
         E.w = edgeW; E.gacc = edgeG; E.lane = lane;
     } else {
@@ -88,8 +95,11 @@ __global__ __launch_bounds__(64 * kBwdWaves, (sizeof(R) == 4 ? 2 : 1)) void solv
     }
     OdeP<R> o;
     ode_load(o, a.ode_p + 17 * set);
-    wt_rot_store<R>(wt, nn_set, a.H, NL - 1, threadIdx.x, 64 * kBwdWaves);
-    tableau_rowsT_store<R>(rowsT, method, threadIdx.x, 64 * kBwdWaves);
+    using WtPol = std::conditional_t<WTREG, WtRegs<NL>, WtLds<R>>;
+    WtPol wtp;
+    if constexpr (WTREG) wtp.load(nn_set, a.H, lane);
+    else { wt_rot_store<R>(wt, nn_set, a.H, NL - 1, threadIdx.x, 64 * kWaves); wtp.wt = wt; }
+    tableau_rowsT_store<R>(rowsT, method, threadIdx.x, 64 * kWaves);
     __syncthreads();
 
     R gwh[(NL > 1) ? NL - 1 : 1][kMaxH];
@@ -101,8 +111,24 @@ __global__ __launch_bounds__(64 * kBwdWaves, (sizeof(R) == 4 ? 2 : 1)) void solv
 #pragma unroll
     for (int i = 0; i < 17; ++i) go[i] = R(0);
     const bool use_gd = a.gd_mode != 0;
+    R *rec = rowsT + 8 * kWave + (kEdgeLds<R> ? (size_t)(1 + kBwdWaves) * EdgeSlots<NL>::count * kWave : 0) +
+             (size_t)wave * 2 * kSlot;
+    // one record = (NL + 1) rows of 64 reals; each row is one (fp32) or two (fp64) 4-byte-per-lane DMA instructions
+    auto rec_dma = [&](const R *__restrict__ src, R *dst) {
+#pragma unroll
+        for (int l = 0; l <= NL; ++l) {
+            if constexpr (sizeof(R) == 4) {
+                __builtin_amdgcn_global_load_lds(src + l * kWave + lane, (__attribute__((address_space(3))) void *)(dst + l * kWave), 4, 0, 0);
+            } else {
+                const float *s32 = reinterpret_cast<const float *>(src + l * kWave);
+                float *d32 = reinterpret_cast<float *>(dst + l * kWave);
+                __builtin_amdgcn_global_load_lds(s32 + lane, (__attribute__((address_space(3))) void *)d32, 4, 0, 0);
+                __builtin_amdgcn_global_load_lds(s32 + kWave + lane, (__attribute__((address_space(3))) void *)(d32 + kWave), 4, 0, 0);
+            }
+        }
+    };
 
-    for (int bi = blockIdx.x * kBwdWaves + wave; bi < per_set; bi += gridDim.x * kBwdWaves) {
+    for (int bi = blockIdx.x * kWaves + wave; bi < per_set; bi += gridDim.x * kWaves) {
         const int b = set * per_set + bi;
         const R *__restrict__ tg = a.t + (a.t_batched ? (size_t)b * T : 0);
         const R *__restrict__ tape = a.tape + (size_t)b * a.max_steps * 8;
@@ -113,13 +139,23 @@ __global__ __launch_bounds__(64 * kBwdWaves, (sizeof(R) == 4 ? 2 : 1)) void solv
         const bool ok = a.status[b] == HODE_ST_OK;
         R lam = R(0);                              // cotangent of the state, replicated per 8-lane group
         int knext = T - 1;                         // grid interval of the step after the current one
+        // Stage records stream HBM -> LDS by DMA (no VGPR destination): while stage s is processed from one
+        // half of the wave's double buffer, the record of the next stage (also across step boundaries) lands
+        // in the other half.
+        int cur = 0;
+        if (n > 0) rec_dma(stg + ((size_t)(n - 1) * 6 + (S - 1)) * kSlot, rec);
 #pragma unroll 1
         for (int st = n - 1; st >= 0; --st) {
             const int k = tseg[st];
             // cotangents of the grid rows this step produced (row k+1 and any repeated rows).  A failed
             // trajectory's unfinished last interval was never written to y: it injects nothing.
             const int hi = (st == n - 1) ? (ok ? T - 1 : k) : knext;
-            for (int r = k + 1; r <= hi; ++r) lam += (c8 < 6) ? gyb[(size_t)r * 6 + c8] : R(0);
+            for (int r = k + 1; r <= hi; ++r) {
+                // six wave-uniform (scalar) loads + selects: vector-memory traffic stays reserved for the DMAs
+                const R *__restrict__ gr = gyb + (size_t)r * 6;
+                const R g0 = gr[0], g1 = gr[1], g2 = gr[2], g3 = gr[3], g4 = gr[4], g5 = gr[5];
+                lam += (c8 == 0) ? g0 : (c8 == 1) ? g1 : (c8 == 2) ? g2 : (c8 == 3) ? g3 : (c8 == 4) ? g4 : (c8 == 5) ? g5 : R(0);
+            }
             knext = k;
             const R tc = tape[(size_t)st * 8 + 0], h = tape[(size_t)st * 8 + 1];
             const R t0 = tg[k], t1 = tg[k + 1];
@@ -129,38 +165,27 @@ __global__ __launch_bounds__(64 * kBwdWaves, (sizeof(R) == 4 ? 2 : 1)) void solv
             const R dv = first_lane(v1 - v0), dd = first_lane(d1 - d0);
 
             // reverse sweep over the stages.  kb_s = h (b_s lam + sum_{j>s} a_js Z_j),  Z_s = J_s^T kb_s
-            const R *__restrict__ slot = stg + ((size_t)st * 6 + (S - 1)) * kSlot + lane;
-            MlpActs<R, NL> ac;
-            R Ys;
-#pragma unroll
-            for (int l = 0; l < NL; ++l) ac.h[l] = slot[l * kWave];
-            Ys = slot[NL * kWave];
             R ZZ = R(0);
 #pragma unroll 1
             for (int s = S - 1; s >= 0; --s) {
-                // prefetch the next (earlier) stage's record while this one is processed
-                MlpActs<R, NL> acn;
-                R Ysn = R(0);
-                if (s > 0) {
-                    const R *__restrict__ sn = slot - kSlot;
+                // record (st, s) was DMA'd into rec[cur] one stage ago: drain the DMA, then start the next one
+                __builtin_amdgcn_s_waitcnt(0x0f70);            // vmcnt(0): the only outstanding VMEM ops are our DMAs
+                __builtin_amdgcn_wave_barrier();
+                const int nst = (s > 0) ? st : st - 1, ns_ = (s > 0) ? s - 1 : S - 1;
+                if (nst >= 0) rec_dma(stg + ((size_t)nst * 6 + ns_) * kSlot, rec + (cur ^ 1) * kSlot);
+                MlpActs<R, NL> ac;
 #pragma unroll
-                    for (int l = 0; l < NL; ++l) acn.h[l] = sn[l * kWave];
-                    Ysn = sn[NL * kWave];
-                } else {
-#pragma unroll
-                    for (int l = 0; l < NL; ++l) acn.h[l] = R(0);
-                }
+                for (int l = 0; l < NL; ++l) ac.h[l] = rec[cur * kSlot + l * kWave + lane];
+                const R Ys = rec[cur * kSlot + NL * kWave + lane];
+                cur ^= 1;
                 const R kb = h * rfma((R)tab.bw[s], lam, group_sum8(rowsT[s * kWave + lane] * ZZ));
                 const R ts = rfma((R)tab.c[s], h, tc);
                 const R al = (ts - t0) * inv_len;
                 const R gdv = rfma(al, dd, d0);
                 const R gde = use_gd ? gd_effect(o, gdv) : R(0);
-                const R Z = rhs_vjp<R, NL, GODE, false>(E, gwh, wt, o, ts, Ys, rfma(al, dv, v0), gde, gdv, use_gd, lane, ac, kb,
+                const R Z = rhs_vjp<R, NL, GODE, false>(E, gwh, wtp, o, ts, Ys, rfma(al, dv, v0), gde, gdv, use_gd, lane, ac, kb,
                                                         go, nullptr);
                 ZZ = (grp == s) ? Z : ZZ;
-                ac = acn;
-                Ys = Ysn;
-                slot -= kSlot;
             }
             lam += group_sum8(rowsT[7 * kWave + lane] * ZZ);
         }
@@ -179,27 +204,38 @@ __global__ __launch_bounds__(64 * kBwdWaves, (sizeof(R) == 4 ? 2 : 1)) void solv
     }
 }
 
-template <typename R, int NL> static int launch_bwd_nl(hipStream_t s, const AdjArgs<R> &a, int method)
+template <typename R, int NL, bool GODE, bool WTREG> static int launch_bwd_k(hipStream_t s, const AdjArgs<R> &a, int method)
 {
+    constexpr int kW = WTREG ? 4 : kBwdWaves;
     const int per_set = a.B / a.n_sets;
-    int blocks = (per_set + kBwdWaves - 1) / kBwdWaves;
-    if (blocks > 256) blocks = 256;             // one 8-wave workgroup per CU, waves loop over trajectories
+    int blocks = (per_set + kW - 1) / kW;
+    if (blocks > 256) blocks = 256;             // one workgroup per CU, waves loop over trajectories
     if (a.n_sets > 1 && blocks * a.n_sets > 256) blocks = (256 + a.n_sets - 1) / a.n_sets;
     if (blocks < 1) blocks = 1;
     const size_t lds = bwd_lds_elems<R, NL>() * sizeof(R);
-    dim3 grid(blocks, a.n_sets), block(64 * kBwdWaves);
-    if (a.gode) {
-        auto kern = solve_bwd_kernel<R, NL, true>;
-        if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return HODE_ELAUNCH;
-        hipLaunchKernelGGL(kern, grid, block, lds, s, a, method);
-    } else {
-        auto kern = solve_bwd_kernel<R, NL, false>;
-        if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return HODE_ELAUNCH;
-        hipLaunchKernelGGL(kern, grid, block, lds, s, a, method);
-    }
+    dim3 grid(blocks, a.n_sets), block(64 * kW);
+    auto kern = solve_bwd_kernel<R, NL, GODE, WTREG>;
+    if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return HODE_ELAUNCH;
+    hipLaunchKernelGGL(kern, grid, block, lds, s, a, method);
     return hipGetLastError() == hipSuccess ? HODE_OK : HODE_ELAUNCH;
+}
+
+// fp32 default: transposed matrices in LDS, 2 waves/SIMD (measured 11.0 ms per 4096x241 adjoint).
+// HODE_BWD_WT=regs selects the register-resident variant (1 wave/SIMD, 13.9 ms) for comparison.
+static bool bwd_wt_in_regs()
+{
+    static const bool v = [] { const char *e = getenv("HODE_BWD_WT"); return e && e[0] == 'r'; }();
+    return v;
+}
+
+template <typename R, int NL> static int launch_bwd_nl(hipStream_t s, const AdjArgs<R> &a, int method)
+{
+    if constexpr (sizeof(R) == 4) {
+        if (bwd_wt_in_regs())
+            return a.gode ? launch_bwd_k<R, NL, true, true>(s, a, method) : launch_bwd_k<R, NL, false, true>(s, a, method);
+    }
+    return a.gode ? launch_bwd_k<R, NL, true, false>(s, a, method) : launch_bwd_k<R, NL, false, false>(s, a, method);
 }
 
 template <typename R> int launch_solve_bwd(hipStream_t s, const AdjArgs<R> &a, int L, int method)
@@ -258,7 +294,7 @@ __global__ __launch_bounds__(256, 1) void rhs_bwd_kernel(const RhsArgs<R> a)
         MlpActs<R, NL> ac;
         (void)rhs_eval<R, NL, true>(W, o, t, Y, meal, tvns, gde, lane, &ac);
         R gt;
-        const R Z = rhs_vjp<R, NL, GODE, true>(E, gwh, wt, o, t, Y, tvns, gde, gdv, a.gd != nullptr, lane, ac, kb, go, &gt);
+        const R Z = rhs_vjp<R, NL, GODE, true>(E, gwh, WtLds<R>{wt}, o, t, Y, tvns, gde, gdv, a.gd != nullptr, lane, ac, kb, go, &gt);
         if (lane < 6) a.gx[(size_t)s * 6 + lane] = Z;
         if (a.gt && lane == 0) a.gt[s] = gt;
     }

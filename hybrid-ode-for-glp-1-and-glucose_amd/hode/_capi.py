@@ -6,7 +6,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libhode.so")
+_SO = os.environ.get("HODE_LIB") or os.path.join(_HERE, "libhode.so")   # HODE_LIB: development builds
 _lib = None
 
 METHOD_DP54 = 0
