@@ -25,6 +25,7 @@ template <typename R, int NL, int METHOD, int LB, bool TAPE>
 __global__ __launch_bounds__(64, LB) void solve_fwd_kernel(const SolveArgs<R> a)
 {
     __shared__ R rows[8 * kWave];             // tableau coefficient rows (hode_device.h)
+    __shared__ R ybuf[kWave + 8];             // output staging: rows of 6 reals are gathered into 256-byte stores
     const int lane = threadIdx.x;
     const int c8 = lane & 7, grp = lane >> 3;
     const int b = blockIdx.x;                 // one wave == one trajectory
@@ -50,7 +51,30 @@ __global__ __launch_bounds__(64, LB) void solve_fwd_kernel(const SolveArgs<R> a)
 
     // state, replicated over the eight 8-lane groups: lane l holds y_{l&7}
     R Y = (c8 < 6) ? a.x0[(size_t)b * 6 + c8] : R(0);
-    if (lane < 6) yb[lane] = Y;
+    // y[b, k, 0:6] is a contiguous stream of 6 T reals: rows are staged in LDS and leave as full 64-lane
+    // stores (a 24-byte store per grid point costs a partial cache line each: measured 1.9x write traffic)
+    int ypos = 0;                             // staged reals
+    size_t ybase = 0;                         // reals already written
+    auto y_put = [&](R v) {
+        if (lane < 6) ybuf[ypos + lane] = v;
+        ypos += 6;
+        if (ypos >= kWave) {
+            __builtin_amdgcn_wave_barrier();
+            yb[ybase + lane] = ybuf[lane];
+            const R carry = (lane < 8) ? ybuf[kWave + lane] : R(0);
+            __builtin_amdgcn_wave_barrier();
+            if (lane < 8) ybuf[lane] = carry;
+            ybase += kWave;
+            ypos -= kWave;
+        }
+    };
+    auto y_flush = [&]() {
+        __builtin_amdgcn_wave_barrier();
+        if (lane < ypos) yb[ybase + lane] = ybuf[lane];
+        ybase += ypos;
+        ypos = 0;
+    };
+    y_put(Y);
 
     int st = HODE_ST_OK, ns = 0, nf = 0, k = 0;
     R h_abs = R(0);
@@ -64,7 +88,7 @@ __global__ __launch_bounds__(64, LB) void solve_fwd_kernel(const SolveArgs<R> a)
         const R d0 = inp_at(a.gd, a.gd_mode, b, T, k), d1 = inp_at(a.gd, a.gd_mode, b, T, k + 1);
         const R len = t1 - t0;
         if (!(len > R(0))) {                  // repeated grid time: copy the state
-            if (lane < 6) yb[(size_t)(k + 1) * 6 + lane] = Y;
+            y_put(Y);
             continue;
         }
         const R inv_len = first_lane(R(1) / len);
@@ -182,14 +206,14 @@ __global__ __launch_bounds__(64, LB) void solve_fwd_kernel(const SolveArgs<R> a)
         if (st == HODE_ST_OK) {
             const float ysum = (float)first_lane(oct_allsum(Y));
             if (!(fabsf(ysum) <= 3.0e38f)) st = HODE_ST_NONFINITE;
-            else if (lane < 6) yb[(size_t)(k + 1) * 6 + lane] = Y;
+            else y_put(Y);
         }
         if (st != HODE_ST_OK) break;
     }
+    y_flush();
     if (st != HODE_ST_OK) {
         // rows from the failed interval on stay zero (models/hybrid_ode_nn.py:243-256)
-        for (int r = k + 1; r < T; ++r)
-            if (lane < 6) yb[(size_t)r * 6 + lane] = R(0);
+        for (size_t i = ybase + lane; i < (size_t)T * 6; i += kWave) yb[i] = R(0);
     }
     if (lane == 0) {
         a.status[b] = st;
