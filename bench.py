@@ -101,7 +101,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--patients-per-gpu", type=int, default=4096)
     ap.add_argument("--train-steps", type=int, default=5)
-    ap.add_argument("--cpu-sample", type=int, default=16384)
+    ap.add_argument("--cpu-sample", type=int, default=65536)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true")
     args = ap.parse_args()

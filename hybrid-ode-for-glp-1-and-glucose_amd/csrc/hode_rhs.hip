@@ -14,8 +14,9 @@ __global__ __launch_bounds__(256) void rhs_fwd_kernel(const RhsArgs<R> a)
 {
     const int lane = threadIdx.x & 63;
     const int wave = first_lane((int)(threadIdx.x >> 6));
+    __shared__ R wstage[(sizeof(R) == 4) ? 4 * kStageElems : 1];
     MlpRegs<R, NL> W;
-    mlp_load<R, NL>(W, a.nn_p, a.H, lane);
+    mlp_load<R, NL>(W, a.nn_p, a.H, lane, wstage + ((sizeof(R) == 4) ? wave * kStageElems : 0));
     OdeP<R> o;
     ode_load(o, a.ode_p);
     const int stride = gridDim.x * 4;

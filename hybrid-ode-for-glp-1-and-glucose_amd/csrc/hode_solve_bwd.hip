@@ -303,9 +303,10 @@ __global__ __launch_bounds__(256, 1) void rhs_bwd_kernel(const RhsArgs<R> a)
     const int lane = threadIdx.x & 63;
     const int wave = first_lane((int)(threadIdx.x >> 6));
     MlpRegs<R, NL> W;
-    mlp_load<R, NL>(W, a.nn_p, a.H, lane);
+    mlp_load<R, NL>(W, a.nn_p, a.H, lane, wt + (size_t)wave * kStageElems);   // the image area doubles as staging
     OdeP<R> o;
     ode_load(o, a.ode_p);
+    __syncthreads();
     wt_rot_store<R>(wt, a.nn_p, a.H, NL - 1, threadIdx.x, 256);
     __syncthreads();
     using ES = EdgeSlots<NL>;
@@ -356,7 +357,8 @@ template <typename R, int NL> static int launch_rhs_bwd_nl(hipStream_t s, const 
     int blocks = (a.B + 3) / 4;
     if (blocks > 256) blocks = 256;
     if (blocks < 1) return HODE_OK;
-    const size_t lds = (size_t)(NL > 1 ? NL - 1 : 1) * kMaxH * kMaxH * sizeof(R);
+    size_t lds = (size_t)(NL > 1 ? NL - 1 : 1) * kMaxH * kMaxH * sizeof(R);
+    if (lds < 4 * (size_t)kStageElems * sizeof(R)) lds = 4 * (size_t)kStageElems * sizeof(R);
     if (a.gode) {
         auto kern = rhs_bwd_kernel<R, NL, true>;
         if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)

@@ -26,6 +26,7 @@ __global__ __launch_bounds__(64, LB) void solve_fwd_kernel(const SolveArgs<R> a)
 {
     __shared__ R rows[8 * kWave];             // tableau coefficient rows (hode_device.h)
     __shared__ R ybuf[kWave + 8];             // output staging: rows of 6 reals are gathered into 256-byte stores
+    __shared__ R wstage[(sizeof(R) == 4) ? kStageElems : 1];   // weight-row permutation scratch (prologue only)
     const int lane = threadIdx.x;
     const int c8 = lane & 7, grp = lane >> 3;
     const int b = blockIdx.x;                 // one wave == one trajectory
@@ -34,7 +35,7 @@ __global__ __launch_bounds__(64, LB) void solve_fwd_kernel(const SolveArgs<R> a)
 
     tableau_rows_store<R>(rows, METHOD, lane, 64);
     MlpRegs<R, NL> W;
-    mlp_load<R, NL>(W, a.nn_p + (size_t)set * a.P, a.H, lane);
+    mlp_load<R, NL>(W, a.nn_p + (size_t)set * a.P, a.H, lane, wstage);
     OdeP<R> o;
     ode_load(o, a.ode_p + 17 * set);
     __syncthreads();
