@@ -104,6 +104,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=65536)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, default) | gloo (rehearsal: ranks may share one GPU)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -115,11 +116,16 @@ def main():
         raise SystemExit("for --gpus N > 1 launch with torch.distributed.run (one rank per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank if args.backend == "nccl" else local_rank % ndev
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)      # "nccl" is RCCL on ROCm
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)      # "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group("gloo")                     # rehearsal only (collectives staged through the host)
 
     import hode
     hode.load()
@@ -129,9 +135,19 @@ def main():
     ode = ODE_DEFAULT.to(dev)
 
     def barrier():
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def allreduce_max(tensor):
+        if world > 1:
+            if args.backend == "nccl":
+                dist.all_reduce(tensor, op=dist.ReduceOp.MAX)
+            else:
+                c = tensor.cpu()
+                dist.all_reduce(c, op=dist.ReduceOp.MAX)
+                tensor.copy_(c)
 
     # ------------------------------------------------------------------ headline: forward solve
     def fwd_step():
@@ -150,8 +166,7 @@ def main():
     wall = time.perf_counter() - t0
     kern_ms = e0.elapsed_time(e1) / args.steps
     tm = torch.tensor([wall], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+    allreduce_max(tm)
     wall = float(tm)
     nfev = float(sol.nfev.double().sum())
     nsteps = float(sol.nsteps.double().sum())
@@ -171,15 +186,15 @@ def main():
             ls, gnn, gode, _ = hode.train.hip_loss_and_grads(p, ode, x0, t, meal, tvns, obs, H, L, n_glob, state=state)
             return ls, gnn, gode, B * T * 6
 
-        losses = [float(hode.train.train_step(state, compute)) for _ in range(2)]       # warm-up
+        ts_kw = {} if args.backend == "nccl" else {"host_staged": True}
+        losses = [float(hode.train.train_step(state, compute, **ts_kw)) for _ in range(2)]       # warm-up
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.train_steps):
-            loss = hode.train.train_step(state, compute)
+            loss = hode.train.train_step(state, compute, **ts_kw)
         barrier()
         tw = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
-        if world > 1:
-            dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+        allreduce_max(tw)
         losses.append(float(loss))
         train = {"metric": "patient-trajectories/s (fwd + adjoint + all-reduce + fused Adam)",
                  "value": world * B * args.train_steps / float(tw), "ms_per_step": float(tw) / args.train_steps * 1e3,

@@ -16,6 +16,7 @@ int solve_fwd(void *stream, int B, int T, const R *x0, const R *t, int t_batched
               int H, int L, int method, double rtol, double atol, int max_steps, R *y, int32_t *status,
               int32_t *nsteps, int32_t *nfev, void *tape)
 {
+    if (B == 0 && T >= 1) return HODE_OK;                     // an empty batch is valid (empty tensors have null data)
     if (B < 0 || T < 1 || !x0 || !t || !ode_p || !nn_p || !y || !status) return HODE_EINVAL;
     if (!mode_ok(meal_mode, meal) || !mode_ok(tvns_mode, tvns) || !mode_ok(gd_mode, gd)) return HODE_EINVAL;
     if (n_sets < 1 || (B % n_sets) != 0 || max_steps < 1) return HODE_EINVAL;
@@ -41,6 +42,7 @@ template <typename R>
 int rhs_fwd(void *stream, int B, const R *x, const R *t, const R *meal, const R *tvns, const R *gd, const R *ode_p,
             const R *nn_p, int H, int L, R *out)
 {
+    if (B == 0) return HODE_OK;
     if (B < 0 || !x || !ode_p || !nn_p || !out) return HODE_EINVAL;
     if (H < 1 || H > HODE_MAX_HIDDEN || L < 1 || L > HODE_MAX_LAYERS) return HODE_EUNSUPPORTED;
     if (B == 0) return HODE_OK;
@@ -56,6 +58,7 @@ int solve_bwd(void *stream, int B, int T, const R *t, int t_batched, const R *me
               int method, int max_steps, const int32_t *nsteps, const int32_t *status, const void *tape, const R *gy,
               R *gx0, R *gnn, R *gode)
 {
+    if (B == 0 && T >= 1) return HODE_OK;
     if (B < 0 || T < 1 || !t || !ode_p || !nn_p || !nsteps || !status || !tape || !gy || !gx0) return HODE_EINVAL;
     if (!mode_ok(meal_mode, meal) || !mode_ok(tvns_mode, tvns) || !mode_ok(gd_mode, gd)) return HODE_EINVAL;
     if (n_sets < 1 || (B % n_sets) != 0 || max_steps < 1) return HODE_EINVAL;
@@ -79,6 +82,7 @@ template <typename R>
 int rhs_bwd(void *stream, int B, const R *x, const R *t, const R *meal, const R *tvns, const R *gd, const R *ode_p,
             const R *nn_p, int H, int L, const R *gout, R *gx, R *gt, R *gnn, R *gode)
 {
+    if (B == 0) return HODE_OK;
     if (B < 0 || !x || !ode_p || !nn_p || !gout || !gx) return HODE_EINVAL;
     if (H < 1 || H > HODE_MAX_HIDDEN || L < 1 || L > HODE_MAX_LAYERS) return HODE_EUNSUPPORTED;
     if (B == 0) return HODE_OK;

@@ -77,15 +77,21 @@ def hip_loss_and_grads(p, ode_p, x0, t, meal, tvns, obs, H, L, n_elem_global, rt
 
 def train_step(state: TrainState, compute: Callable[[torch.Tensor], Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor], float]],
                lr: float = 1e-3, max_norm: float = 5.0, betas=(0.9, 0.999), eps: float = 1e-8,
-               group=None, optimizer: Optional[Callable] = None) -> float:
+               group=None, optimizer: Optional[Callable] = None, host_staged: bool = False) -> float:
     """One optimisation step.  `compute(p)` -> (loss_sum, gnn, gode|None, n_local_elements) for the local shard
     (gradients already scaled for the global mean).  Returns the global mean loss.
-    `optimizer(state, g)` overrides the fused HIP Adam (used by the CPU/gloo tests)."""
+    `optimizer(state, g)` overrides the fused HIP Adam (used by the CPU/gloo tests); `host_staged` routes the
+    collective through host memory (gloo rehearsal of the multi-rank path on a single GPU)."""
     P = state.p.numel()
     loss_sum, gnn, gode, n_local = compute(state.p)
     buf = pack(gnn, gode, loss_sum, n_local)
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)      # the step's only collective
+        if host_staged:                                               # gloo rehearsal with device tensors
+            host = buf.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+            buf.copy_(host)
+        else:
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)  # the step's only collective
     g, _gode, lsum, n_tot = unpack(buf, P)
     state.step += 1
     if optimizer is not None:

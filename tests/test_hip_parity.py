@@ -335,3 +335,118 @@ def test_mse_fwd_bwd(hode):
         ref = ((y.double() - obs.double()) ** 2).sum()
         assert abs(float(loss) - float(ref)) < 1e-6 * float(ref) + 1e-12   # squares in fp32, sum in fp64
         assert torch.allclose(gy, 2 * (y - obs) / y.numel(), rtol=1e-6, atol=1e-9)
+
+
+# ============================================================================== edge cases / full size
+def _rand_net(H, L, seed):
+    rng = np.random.default_rng(seed)
+    P = 9 * H + H + (L - 1) * (H * H + H) + 6 * H + 6
+    return (0.1 * rng.standard_normal(P)).astype(np.float32)
+
+
+@pytest.mark.parametrize("H,L", [(16, 1), (48, 3), (64, 2), (7, 4)])
+def test_network_shapes_fwd_bwd(hode, golden_dir, g0, H, L):
+    """Hidden widths < 64 (zero padded lanes) and 1..4 hidden layers: forward + adjoint vs oracle (fp64)."""
+    g = np.load(os.path.join(golden_dir, "g4_t61_rand.npz"))
+    nn = _rand_net(H, L, H * 10 + L)
+    x0, t, meal, tv = g["x0"][:3], g["t"][:21], g["meal"][:3, :21], g["tvns"][:3, :21]
+    c = np.random.default_rng(1).standard_normal((3, 21, 6))
+    ref = O.solve(x0, t, meal, tv, None, g0["ode"], nn, H, L, rtol=1e-8, atol=1e-10, dtype=np.float64, want_tape=True)
+    rx, rnn, rode = O.solve_bwd(ref, c)
+    dt = torch.float64
+    s = hode.solve_fwd(dev(x0, dt), dev(t, dt), dev(meal, dt), dev(tv, dt), None, dev(g0["ode"], dt), dev(nn, dt), H, L,
+                       rtol=1e-8, atol=1e-10, want_tape=True)
+    gx0, gnn, gode = hode.solve_bwd(s, dev(c, dt), want_gode=True)
+    assert rel(s.y.cpu().numpy(), ref.y) < 1e-9
+    assert relnorm(gx0.cpu().numpy(), rx) < 1e-8 and relnorm(gnn.cpu().numpy(), rnn) < 1e-8
+    assert relnorm(gode.cpu().numpy(), rode) < 1e-8
+    # fp32 through the same shapes
+    s32 = hode.solve_fwd(dev(x0, torch.float32), dev(t, torch.float32), dev(meal, torch.float32), dev(tv, torch.float32),
+                         None, dev(g0["ode"], torch.float32), dev(nn, torch.float32), H, L, want_tape=True)
+    _, gnn32, _ = hode.solve_bwd(s32, dev(c, torch.float32))
+    # random N(0, 0.1) weights on raw states (~80) put many hidden units next to their ReLU kink, where the
+    # gradient is discontinuous: fp32 rounding flips a few of them, so this is a sanity bound, not the 1e-4 bar
+    assert rel(s32.y.cpu().numpy(), ref.y) < 1e-3 and relnorm(gnn32.cpu().numpy(), rnn) < 2e-2
+
+
+@pytest.mark.parametrize("B,T", [(1, 2), (1, 61), (9, 3), (13, 17)])
+def test_ragged_batch_sizes(hode, golden_dir, g0, B, T):
+    """B = 1, B not a multiple of the adjoint's 8-wave workgroups, T = 2 (a single interval)."""
+    rng = np.random.default_rng(B * 100 + T)
+    x0 = np.array([5, 60, 80, 10, 0, 1.0]) * (1 + 0.05 * rng.standard_normal((B, 6)))
+    t = np.linspace(0, 0.25 * (T - 1), T)
+    meal = rng.random((B, T))
+    c = rng.standard_normal((B, T, 6))
+    ref = O.solve(x0, t, meal, None, None, g0["ode"], g0["nn"], 64, 4, rtol=1e-8, atol=1e-10, dtype=np.float64, want_tape=True)
+    rx, rnn, _ = O.solve_bwd(ref, c)
+    dt = torch.float64
+    s = hode.solve_fwd(dev(x0, dt), dev(t, dt), dev(meal, dt), None, None, dev(g0["ode"], dt), dev(g0["nn"], dt), 64, 4,
+                       rtol=1e-8, atol=1e-10, want_tape=True)
+    gx0, gnn, _ = hode.solve_bwd(s, dev(c, dt))
+    assert rel(s.y.cpu().numpy(), ref.y) < 1e-9
+    assert relnorm(gx0.cpu().numpy(), rx) < 1e-8 and relnorm(gnn.cpu().numpy(), rnn) < 1e-8
+
+
+def test_empty_batch_and_repeated_times(hode, g0):
+    dt = torch.float64
+    s = hode.solve_fwd(torch.zeros(0, 6, dtype=dt, device="cuda"), dev(np.linspace(0, 1, 5), dt), None, None, None,
+                       dev(g0["ode"], dt), dev(g0["nn"], dt), 64, 4)
+    assert tuple(s.y.shape) == (0, 5, 6)
+    # a repeated grid time is a zero-length interval: the state is copied, its cotangent flows through
+    x0 = np.array([[5, 60, 80, 10, 0, 1.0], [6, 50, 70, 12, 0.1, 0.9]])
+    t = np.array([0.0, 0.1, 0.1, 0.3, 0.3, 0.3, 0.5])
+    meal = np.random.default_rng(2).random((2, 7))
+    c = np.random.default_rng(3).standard_normal((2, 7, 6))
+    ref = O.solve(x0, t, meal, None, None, g0["ode"], g0["nn"], 64, 4, rtol=1e-8, atol=1e-10, dtype=np.float64, want_tape=True)
+    rx, rnn, _ = O.solve_bwd(ref, c)
+    s = hode.solve_fwd(dev(x0, dt), dev(t, dt), dev(meal, dt), None, None, dev(g0["ode"], dt), dev(g0["nn"], dt), 64, 4,
+                       rtol=1e-8, atol=1e-10, want_tape=True)
+    y = s.y.cpu().numpy()
+    assert np.array_equal(y[:, 1], y[:, 2]) and np.array_equal(y[:, 3], y[:, 5]) and rel(y, ref.y) < 1e-9
+    gx0, gnn, _ = hode.solve_bwd(s, dev(c, dt))
+    assert relnorm(gx0.cpu().numpy(), rx) < 1e-8 and relnorm(gnn.cpu().numpy(), rnn) < 1e-8
+
+
+def test_constant_inputs_and_gd_through_solve(hode, golden_dir, g0):
+    """mode-1 (constant per patient) inputs and a time-varying GD signal (Hill term, pow) in solve + adjoint."""
+    g = np.load(os.path.join(golden_dir, "g4_t61_const.npz"))
+    rng = np.random.default_rng(8)
+    B, T = 4, 31
+    x0, t = g["x0"][:B], g["t"][:T]
+    meal, tv = g["meal"][:B], g["tvns"][:B]                  # [B] constants
+    gd = 200.0 + 800.0 * rng.random((B, T))
+    c = rng.standard_normal((B, T, 6))
+    ref = O.solve(x0, t, meal, tv, gd, g0["ode"], g0["nn"], 64, 4, rtol=1e-8, atol=1e-10, dtype=np.float64, want_tape=True)
+    rx, rnn, rode = O.solve_bwd(ref, c)
+    dt = torch.float64
+    s = hode.solve_fwd(dev(x0, dt), dev(t, dt), dev(meal, dt), dev(tv, dt), dev(gd, dt), dev(g0["ode"], dt),
+                       dev(g0["nn"], dt), 64, 4, rtol=1e-8, atol=1e-10, want_tape=True)
+    gx0, gnn, gode = hode.solve_bwd(s, dev(c, dt), want_gode=True)
+    assert rel(s.y.cpu().numpy(), ref.y) < 1e-9
+    assert relnorm(gx0.cpu().numpy(), rx) < 1e-8 and relnorm(gnn.cpu().numpy(), rnn) < 1e-8
+    assert relnorm(gode.cpu().numpy(), rode) < 1e-7
+
+
+def test_full_size_properties(hode, g0):
+    """BASELINE config[1] size (4 096 x 241, fp32): properties that do not need the oracle at full size.
+    (i) bit-reproducible run to run, (ii) trajectories are independent: any sub-batch gives bitwise the same
+    rows, (iii) the oracle agrees on a 32-patient sample, (iv) gradients add over a split of the batch."""
+    import bench
+    x0, t, meal, tv = (v.cuda() for v in bench.synth_cohort(4096, 77))
+    nn, ode = bench.synth_weights(0).cuda(), bench.ODE_DEFAULT.cuda()
+    a = hode.solve_fwd(x0, t, meal, tv, None, ode, nn, 64, 4, want_tape=True)
+    b2 = hode.solve_fwd(x0, t, meal, tv, None, ode, nn, 64, 4)
+    assert int(a.status.max()) == 0 and torch.equal(a.y, b2.y)
+    idx = torch.randperm(4096, generator=torch.Generator().manual_seed(1))[:500].cuda()
+    sub = hode.solve_fwd(x0[idx], t, meal[idx], tv[idx], None, ode, nn, 64, 4)
+    assert torch.equal(sub.y, a.y[idx])
+    ref = O.solve(x0[:32].cpu().numpy(), t.cpu().numpy(), meal[:32].cpu().numpy(), tv[:32].cpu().numpy(), None,
+                  ode.cpu().numpy(), nn.cpu().numpy(), 64, 4, rtol=1e-10, atol=1e-12, dtype=np.float64)
+    assert rel(a.y[:32].cpu().numpy(), ref.y) < 1e-4
+    gy = torch.randn(4096, 241, 6, device="cuda", generator=torch.Generator("cuda").manual_seed(5)) / 4096
+    _, gall, _ = hode.solve_bwd(a, gy)
+    h1 = hode.solve_fwd(x0[:1000], t, meal[:1000], tv[:1000], None, ode, nn, 64, 4, want_tape=True)
+    h2 = hode.solve_fwd(x0[1000:], t, meal[1000:], tv[1000:], None, ode, nn, 64, 4, want_tape=True)
+    _, g1, _ = hode.solve_bwd(h1, gy[:1000])
+    _, g2, _ = hode.solve_bwd(h2, gy[1000:])
+    assert relnorm((g1 + g2).cpu().numpy(), gall.cpu().numpy()) < 1e-5
