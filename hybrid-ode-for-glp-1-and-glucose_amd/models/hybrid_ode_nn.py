@@ -295,6 +295,41 @@ class HybridODENN(nn.Module):
         y = y.reshape(S, B, y.shape[1], 6).to(self.device)
         return y[:, 0] if single else y
 
+    # ------------------------------------------------------------------ ELBO (BASELINE config 5)
+    def elbo(self, batch: Dict[str, torch.Tensor], n_samples: int = 16, noise_sigma: float = 0.1,
+             solver: str = "dopri5", rtol: float = 1e-6, atol: float = 1e-8) -> torch.Tensor:
+        """Monte-Carlo ELBO of reference inference/vi.py:60-118 (`VariationalInference.elbo`):
+             E_q[log p(obs | theta)] - KL[q || p],   theta_s = mu + eps_s * exp(log_sigma),  s = 1..S,
+        one parameter draw shared by the whole batch per sample (vi.py:88-100).  All S x B trajectories are
+        ONE launch (the S draws ride in the kernel's parameter-set dimension) and -- unlike the reference,
+        whose likelihood term is detached -- the reparameterised gradient reaches mu / log_sigma
+        through the adjoint kernel (per-set MLP and ODE-constant gradients).  KL and the likelihood sum are
+        accumulated in fp64."""
+        if not self.use_variational:
+            raise ValueError("Model was not initialized with variational inference")
+        self._check_supported()
+        dev = _compute_device()
+        x0, obs, tp = batch["initial_state"], batch["observations"], batch["time_points"]
+        u = batch.get("external_inputs", None) or {}
+        B, S = x0.shape[0], int(n_samples)
+        draws = self.variational_params.sample(S)                      # reparameterised, differentiable
+        flat = [self._params_on(dev, d) for d in draws]
+        nn_flat = torch.cat([f[0] for f in flat])
+        ode_vec = torch.cat([f[1] for f in flat])
+
+        def rep(v):
+            v = torch.as_tensor(v)
+            return v.repeat(S, *([1] * (v.dim() - 1))) if v.dim() >= 1 and v.shape[0] == B else v
+        tt = torch.as_tensor(tp)
+        y = self._solve(x0.repeat(S, 1), rep(tt) if tt.dim() == 2 else tt, {k: rep(v) for k, v in u.items()}, solver,
+                        rtol, atol, n_sets=S, nn_flat=nn_flat, ode_vec=ode_vec)
+        self._warn_failures(self.last_solve_info)
+        resid = (obs.to(dev, torch.float32).repeat(S, 1, 1) - y).double() / noise_sigma
+        n_obs = obs.numel()
+        log_lik = -0.5 * resid.pow(2).sum() / S - 0.5 * n_obs * torch.log(torch.tensor(2 * torch.pi * noise_sigma ** 2, dtype=torch.float64, device=dev))
+        kl = self.variational_params.kl_divergence().double().to(dev)
+        return (log_lik - kl).to(self.device)
+
     # ------------------------------------------------------------------ loss
     def loss(self, batch: Dict[str, torch.Tensor], lambda1: float = 1.0, lambda2: float = 1.0,
              use_physics_loss: bool = True) -> torch.Tensor:

@@ -277,3 +277,64 @@ def test_forward_with_params_and_param_sets(M, golden_dir):
         assert torch.allclose(allsets[s], one[s], rtol=0, atol=0)
     assert not torch.allclose(one[2], base)
     assert float(m.ode_core.k_L) == pytest.approx(0.02)
+
+
+def test_elbo_value_and_reparameterised_gradient(M):
+    """BASELINE config 5 (VI): S Monte-Carlo parameter draws x B patients in ONE launch, KL in fp64, and a
+    reparameterised gradient through the adjoint (the reference's likelihood term carries none).
+    Checks: value == per-sample forward_with_params evaluation; d ELBO / d mu matches central differences
+    with the SAME noise draws."""
+    torch.manual_seed(0)
+    prior = {f"ode_{n}": {"mean": v, "std": 0.1 * v} for n, v in
+             [("a_GI", 0.0104), ("k_I", 0.025), ("rho", 0.003), ("E_max", 0.1), ("EC_50", 50.0), ("V_max", 9.0), ("K_m", 7.0), ("k_L", 0.02)]}
+    m = M.HybridODENN(nn_hidden=16, nn_layers=2, use_variational=True, prior_params=prior, device="cuda")
+    with torch.no_grad():
+        for n, p in m.variational_params.means.items():
+            if n.startswith("nn_"):
+                p.normal_(0, 0.05)
+        for n, p in m.variational_params.log_stds.items():
+            p.fill_(-3.0 if n.startswith("nn_") else float(np.log(0.02 * prior[n]["mean"])))
+    B, T, S = 3, 13, 4
+    g = torch.Generator().manual_seed(1)
+    batch = {"initial_state": (torch.tensor([5., 60., 80., 10., 0., 1.]) * (1 + 0.05 * torch.randn(B, 6, generator=g))).cuda(),
+             "observations": (torch.tensor([5., 60., 80., 10., 0., 1.]) * (1 + 0.05 * torch.randn(B, T, 6, generator=g))).cuda(),
+             "time_points": (torch.arange(T).float() * (5 / 60)).cuda(),
+             "external_inputs": {"meal": (torch.rand(B, T, generator=g) > 0.8).float().cuda(), "tVNS": torch.zeros(B, T).cuda()}}
+
+    def run(seed=3):
+        torch.manual_seed(seed)
+        return m.elbo(batch, n_samples=S, noise_sigma=0.5)
+
+    e = run()
+    assert e.dtype == torch.float64 and torch.isfinite(e)
+    # value: the same draws evaluated one by one
+    torch.manual_seed(3)
+    draws = m.variational_params.sample(S)
+    ll = 0.0
+    with torch.no_grad():
+        for d in draws:
+            y = m.forward_with_params(d, batch["initial_state"], batch["time_points"], batch["external_inputs"])
+            ll += -0.5 * (((batch["observations"] - y).double() / 0.5) ** 2).sum()
+    ref = ll / S - 0.5 * batch["observations"].numel() * np.log(2 * np.pi * 0.25) - float(m.variational_params.kl_divergence())
+    assert abs(float(e) - float(ref)) < 1e-6 * abs(float(ref))
+    # gradient
+    m.zero_grad()
+    e.backward()
+    vp = m.variational_params
+    for n in vp.param_shapes:
+        assert vp.means[n].grad is not None and torch.isfinite(vp.means[n].grad).all()
+        assert vp.log_stds[n].grad is not None and torch.isfinite(vp.log_stds[n].grad).all()
+    for name, idx, hh in [("ode_k_L", (), None), ("nn_network_2_bias", (1,), 1e-2), ("nn_network_0_weight", (3, 2), 1e-3)]:
+        p = vp.means[name]
+        g_an = float(p.grad[idx])
+        # fp32 trajectories put ~1e-3 of noise on the ELBO value: steps large enough to rise above it
+        # (the first-layer weight multiplies insulin ~ 60: a smaller step keeps the hidden units on their side of the ReLU kink)
+        h = hh if hh is not None else 1e-2 * abs(float(p.data[idx]))
+        with torch.no_grad():
+            p[idx] += h
+            ep = float(run())
+            p[idx] -= 2 * h
+            em = float(run())
+            p[idx] += h
+        fd = (ep - em) / (2 * h)
+        assert abs(fd - g_an) <= 5e-2 * max(abs(fd), 1e-2 * float(vp.means[name].grad.abs().max()) + 1e-9), (name, fd, g_an)
