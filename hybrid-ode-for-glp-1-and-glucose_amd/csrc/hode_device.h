@@ -3,11 +3,12 @@
 // Execution model used throughout: ONE TRAJECTORY PER WAVEFRONT, ONE HIDDEN UNIT PER LANE.
 //   * lane j keeps row j of every hidden weight matrix in VGPRs (weights are loaded once per
 //     trajectory and stay register-resident for all ~1440 RHS evaluations);
-//   * a 64x64 layer is 64 FMAs per lane, the activation of lane k is broadcast to the wave
-//     through v_readlane (SGPR operand of the FMA) -- no LDS round trip, no barrier;
-//   * the 6-vector state and the 7 Runge-Kutta stage derivatives are "lane-distributed":
-//     component i lives in lane i of ONE VGPR, so the stage algebra is one FMA per tableau
-//     entry for all six components;
+//   * a 64x64 layer is 64 FMAs per lane; the activation of lane k reaches lane j as the DPP
+//     row_ror:n operand of the FMA itself ("rotating operand", see mlp_hidden) -- no v_readlane per
+//     element, no LDS round trip, no barrier;
+//   * the 6-vector state is replicated per 8-lane group (lane l holds component l & 7) and the
+//     Runge-Kutta stage derivatives are packed into ONE VGPR (lanes 8s..8s+7 = stage s), so a stage
+//     combination is one multiply by a per-lane coefficient row + a 7-instruction cross-lane sum;
 //   * step-size control is per trajectory == per wave: accept/reject is a wave-uniform branch,
 //     there is no lane divergence and no cross-trajectory coupling.
 // MFMA is deliberately not used (north_star): every layer is a matrix-VECTOR product per
@@ -143,19 +144,6 @@ template <typename R> __device__ __forceinline__ R wave_reduce6_to_lanes(const R
 }
 
 // ------------------------------------------------------------------------------------------
-// Dormand-Prince 5(4) tableau (Dormand & Prince 1980; the pair scipy's RK45 and torchdiffeq's
-// dopri5 implement; scipy/integrate/_ivp/rk.py:377-401)
-template <typename R> struct DP {
-    static constexpr R c2 = R(1) / 5, c3 = R(3) / 10, c4 = R(4) / 5, c5 = R(8) / 9;
-    static constexpr R a21 = R(1) / 5;
-    static constexpr R a31 = R(3) / 40, a32 = R(9) / 40;
-    static constexpr R a41 = R(44) / 45, a42 = R(-56) / 15, a43 = R(32) / 9;
-    static constexpr R a51 = R(19372) / 6561, a52 = R(-25360) / 2187, a53 = R(64448) / 6561, a54 = R(-212) / 729;
-    static constexpr R a61 = R(9017) / 3168, a62 = R(-355) / 33, a63 = R(46732) / 5247, a64 = R(49) / 176, a65 = R(-5103) / 18656;
-    static constexpr R b1 = R(35) / 384, b3 = R(500) / 1113, b4 = R(125) / 192, b5 = R(-2187) / 6784, b6 = R(11) / 84;
-    static constexpr R e1 = R(-71) / 57600, e3 = R(71) / 16695, e4 = R(-71) / 1920, e5 = R(17253) / 339200, e6 = R(-22) / 525, e7 = R(1) / 40;
-};
-
 // sum over the 8 lanes that share (lane & 7), result on all of them
 template <typename R> __device__ __forceinline__ R group_sum8(R v)
 {
@@ -475,65 +463,8 @@ __device__ __forceinline__ R rhs_eval(const MlpRegs<R, NL> &W, const OdeP<R> &o,
 
 // ------------------------------------------------------------------------------------------
 // Backward (VJP) building blocks -- used by K4 (adjoint) and K5 (RHS backward).
-//
-// Register-resident gradient accumulators mirror MlpRegs: lane j owns the gradient of row j.
-template <typename R, int NL> struct MlpGrads {
-    R w1[9];
-    R b[NL];
-    R wh[(NL > 1) ? NL - 1 : 1][kMaxH];
-    R w5[6];
-    R b5;   // lane o < 6: d bout[o]
-};
-template <typename R, int NL> __device__ __forceinline__ void grads_zero(MlpGrads<R, NL> &g)
-{
-#pragma unroll
-    for (int i = 0; i < 9; ++i) g.w1[i] = R(0);
-#pragma unroll
-    for (int l = 0; l < NL; ++l) g.b[l] = R(0);
-#pragma unroll
-    for (int l = 0; l < NL - 1; ++l)
-#pragma unroll
-        for (int k = 0; k < kMaxH; ++k) g.wh[l][k] = R(0);
-#pragma unroll
-    for (int o = 0; o < 6; ++o) g.w5[o] = R(0);
-    g.b5 = R(0);
-}
-
 __device__ __forceinline__ void atomic_add(float *p, float v) { unsafeAtomicAdd(p, v); }
 __device__ __forceinline__ void atomic_add(double *p, double v) { unsafeAtomicAdd(p, v); }
-
-// flush the per-lane accumulators into the flat gradient vector (PyTorch parameters() order)
-template <typename R, int NL>
-__device__ __forceinline__ void grads_flush(const MlpGrads<R, NL> &g, R *__restrict__ gp, int H, int lane)
-{
-    const bool live = lane < H;
-    if (live) {
-#pragma unroll
-        for (int i = 0; i < 9; ++i) atomic_add(gp + lane * 9 + i, g.w1[i]);
-    }
-    gp += 9 * H;
-    if (live) atomic_add(gp + lane, g.b[0]);
-    gp += H;
-#pragma unroll
-    for (int l = 0; l < NL - 1; ++l) {
-        if (live) {
-#pragma unroll
-            for (int k = 0; k < kMaxH; ++k) {
-                const int c = wcol<R>(k, lane);            // register k of lane j is column c (rotated order in fp32)
-                if (c < H) atomic_add(gp + (size_t)lane * H + c, g.wh[l][k]);
-            }
-        }
-        gp += (size_t)H * H;
-        if (live) atomic_add(gp + lane, g.b[l + 1]);
-        gp += H;
-    }
-    if (live) {
-#pragma unroll
-        for (int o = 0; o < 6; ++o) atomic_add(gp + o * H + lane, g.w5[o]);
-    }
-    gp += 6 * H;
-    if (lane < 6) atomic_add(gp + lane, g.b5);
-}
 
 // LDS image of the TRANSPOSED hidden matrices in "rotating operand" order (shared by a workgroup):
 //   wt[l][r >> 2][k][r & 3] = W_l[ (r & 48) | ((k - r) & 15) ][k]        r = 16q + n, k = lane
