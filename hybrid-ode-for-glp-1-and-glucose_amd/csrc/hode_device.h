@@ -589,6 +589,7 @@ __device__ __forceinline__ void layer_bwd_group(float (&gw)[kMaxH], const Vec4<f
 {
     const Vec4<float> w0 = wt4[(4 * G + 0) * kMaxH + lane], w1 = wt4[(4 * G + 1) * kMaxH + lane],
                       w2 = wt4[(4 * G + 2) * kMaxH + lane], w3 = wt4[(4 * G + 3) * kMaxH + lane];
+    __builtin_amdgcn_sched_barrier(0);          // reads are issued HERE, the 16 outer-product FMAs below cover their latency
     constexpr int n = 4 * G;
     gw[0 * 16 + n + 0] = fmac_ror<n + 0>(gw[0 * 16 + n + 0], Rh[0], d);
     gw[1 * 16 + n + 0] = fmac_ror<n + 0>(gw[1 * 16 + n + 0], Rh[1], d);
@@ -606,6 +607,8 @@ __device__ __forceinline__ void layer_bwd_group(float (&gw)[kMaxH], const Vec4<f
     gw[1 * 16 + n + 3] = fmac_ror<n + 3>(gw[1 * 16 + n + 3], Rh[1], d);
     gw[2 * 16 + n + 3] = fmac_ror<n + 3>(gw[2 * 16 + n + 3], Rh[2], d);
     gw[3 * 16 + n + 3] = fmac_ror<n + 3>(gw[3 * 16 + n + 3], Rh[3], d);
+    __builtin_amdgcn_sched_barrier(0);          // (hipcc otherwise hoists the dependent FMAs right behind the reads;
+                                                //  a two-deep pipeline of groups was tried: 32 more live registers spill)
     // rows 4G..4G+3 of the image: r = 16 G + 4 i + c  ->  q = G, n = 4 i + c
     acc[0] = fmac_ror<0>(acc[0], Rd[G], w0.v[0]);
     acc[1] = fmac_ror<1>(acc[1], Rd[G], w0.v[1]);
