@@ -660,11 +660,11 @@ template <typename R, int NL> struct EdgeRegs {
     __device__ __forceinline__ void add(int slot, R v) { gacc[slot] += v; }
     __device__ __forceinline__ void fma(int slot, R a, R b) { gacc[slot] = rfma(a, b, gacc[slot]); }
     __device__ __forceinline__ R G(int slot) const { return gacc[slot]; }
-    // gacc[slot] += v[slot] for all slots
-    __device__ __forceinline__ void add_all(const R (&v)[EdgeSlots<NL>::count])
+    // gacc[slot] += v[slot] for the first N slots
+    template <int N> __device__ __forceinline__ void add_all(const R (&v)[EdgeSlots<NL>::count])
     {
 #pragma unroll
-        for (int i = 0; i < EdgeSlots<NL>::count; ++i) gacc[i] += v[i];
+        for (int i = 0; i < N; ++i) gacc[i] += v[i];
     }
 };
 template <typename R, int NL> struct EdgeLds {
@@ -678,13 +678,13 @@ template <typename R, int NL> struct EdgeLds {
     __device__ __forceinline__ void fma(int slot, R a, R b) { gacc[slot * kWave + lane] = rfma(a, b, gacc[slot * kWave + lane]); }
     __device__ __forceinline__ R G(int slot) const { return gacc[slot * kWave + lane]; }
     // all reads first (one LDS wait instead of one per slot), then the adds, then all writes
-    __device__ __forceinline__ void add_all(const R (&v)[EdgeSlots<NL>::count])
+    template <int N> __device__ __forceinline__ void add_all(const R (&v)[EdgeSlots<NL>::count])
     {
-        R cur[EdgeSlots<NL>::count];
+        R cur[N];
 #pragma unroll
-        for (int i = 0; i < EdgeSlots<NL>::count; ++i) cur[i] = gacc[i * kWave + lane];
+        for (int i = 0; i < N; ++i) cur[i] = gacc[i * kWave + lane];
 #pragma unroll
-        for (int i = 0; i < EdgeSlots<NL>::count; ++i) gacc[i * kWave + lane] = cur[i] + v[i];
+        for (int i = 0; i < N; ++i) gacc[i * kWave + lane] = cur[i] + v[i];
     }
 };
 // edge weights of one parameter set into a [slots][64] table (weights only; accumulators start at 0)
@@ -749,13 +749,15 @@ __device__ __forceinline__ void hidden_flush(const R (&wh)[(NL > 1) ? NL - 1 : 1
 // VJP of rhs_eval.  kb = cotangent of f (replicated layout); returns the cotangent of the state in the
 // same layout and accumulates parameter gradients.  acts = activations of this evaluation (from
 // rhs_eval<KEEP> or from the stage tape).  Needs only the first/last layer weights in registers;
-// the hidden matrices come transposed from LDS (wt).   go[17] (GODE): d/d(ode constants), wave-uniform.
+// the hidden matrices come transposed from LDS (wt).   GODE: also d/d(ode constants) (wave-uniform values).
 template <typename R, int NL, bool GODE, bool GT, typename Edge, typename Wt>
 __device__ __forceinline__ R rhs_vjp(Edge &e, R (&gwh)[(NL > 1) ? NL - 1 : 1][kMaxH], const Wt &wt,
                                      const OdeP<R> &o, R t, R Y, R tvns, R gde, R gd_in, bool use_gd, int lane,
-                                     const MlpActs<R, NL> &acts, R kb, R (&go)[17], R *gt_out)
+                                     const MlpActs<R, NL> &acts, R kb, R &go, R *gt_out)
 {
     using S = EdgeSlots<NL>;
+    // increments of the edge-parameter gradients are collected and applied in ONE batch at the end
+    R inc[S::count];
     const R G = lane_bcast(Y, 0), I = lane_bcast(Y, 1), Glu = lane_bcast(Y, 2), GLP1 = lane_bcast(Y, 3),
             GE = lane_bcast(Y, 4), FFA = lane_bcast(Y, 5);
     const R lG = lane_bcast(kb, 0), lI = lane_bcast(kb, 1), lGlu = lane_bcast(kb, 2), lGLP = lane_bcast(kb, 3),
@@ -773,26 +775,36 @@ __device__ __forceinline__ R rhs_vjp(Edge &e, R (&gwh)[(NL > 1) ? NL - 1 : 1][kM
     const int c8 = lane & 7;
     const R mech = (c8 == 0) ? oG : (c8 == 1) ? oI : (c8 == 2) ? oGlu : (c8 == 3) ? oGLP : (c8 == 5) ? oF : R(0);
     if constexpr (GODE) {
-        go[0] += lI * Pi * (G - o.G_b);
-        go[1] -= lI * (I - o.I_b);
-        go[2] += lI * GLP1 * o.a_GI * (G - o.G_b);
-        go[3] -= lI * Pi * o.a_GI;
-        go[4] += lI * o.k_I + lG * R(0.01);
-        go[5] -= lGlu * GLP1 * r1 * (Glu - o.Glu_b);
-        go[6] += lGlu * o.E_max * GLP1 * r1 * r1 * (Glu - o.Glu_b);
-        go[7] += lGlu * o.E_max * GLP1 * r1 - lG * R(0.005);
-        go[8] += lGLP * G * r2;
-        go[9] -= lGLP * o.V_max * G * r2 * r2;
-        go[10] -= lGLP * GLP1;
-        go[11] -= lG * G * (R(1) - gde);
+        // d f / d(ode constant p) . kb for the 17 constants (wave-uniform values), accumulated LANE-DISTRIBUTED:
+        // lane p < 17 of the single register `go` holds the running sum for constant p (17 separate uniform
+        // accumulators cost 16 more VGPRs, which this kernel does not have)
+        R c[17];
+        c[0] = lI * Pi * (G - o.G_b);
+        c[1] = -lI * (I - o.I_b);
+        c[2] = lI * GLP1 * o.a_GI * (G - o.G_b);
+        c[3] = -lI * Pi * o.a_GI;
+        c[4] = lI * o.k_I + lG * R(0.01);
+        c[5] = -lGlu * GLP1 * r1 * (Glu - o.Glu_b);
+        c[6] = lGlu * o.E_max * GLP1 * r1 * r1 * (Glu - o.Glu_b);
+        c[7] = lGlu * o.E_max * GLP1 * r1 - lG * R(0.005);
+        c[8] = lGLP * G * r2;
+        c[9] = -lGLP * o.V_max * G * r2 * r2;
+        c[10] = -lGLP * GLP1;
+        c[11] = -lG * G * (R(1) - gde);
+        c[12] = R(0);
+        c[13] = R(0);
         if (use_gd && gd_in > R(0)) {
             const R u = rpow(gd_in, o.g), v = rpow(o.IGD_50, o.g), s2 = (v + u) * (v + u);
-            go[12] += lG * o.k_GE0 * G * (-u * o.g * rpow(o.IGD_50, o.g - R(1)) / s2);
-            go[13] += lG * o.k_GE0 * G * (u * v * (rlog(gd_in) - rlog(o.IGD_50)) / s2);
+            c[12] = lG * o.k_GE0 * G * (-u * o.g * rpow(o.IGD_50, o.g - R(1)) / s2);
+            c[13] = lG * o.k_GE0 * G * (u * v * (rlog(gd_in) - rlog(o.IGD_50)) / s2);
         }
-        go[14] -= lF * FFA;
-        go[15] -= lF * I * FFA;
-        go[16] += lF * G * FFA;
+        c[14] = -lF * FFA;
+        c[15] = -lF * I * FFA;
+        c[16] = lF * G * FFA;
+        R sel = R(0);
+#pragma unroll
+        for (int p = 0; p < 17; ++p) sel = (lane == p) ? c[p] : sel;
+        go += sel;
     }
     // ---- MLP backward
     const R hl = acts.h[NL - 1];
@@ -805,8 +817,6 @@ __device__ __forceinline__ R rhs_vjp(Edge &e, R (&gwh)[(NL > 1) ? NL - 1 : 1][kM
     d = rfma(w53, lGLP, d);
     d = rfma(w54, lGE, d);
     d = rfma(w55, lF, d);
-    // increments of the edge-parameter gradients are collected and applied in ONE batch at the end
-    R inc[S::count];
     inc[S::b5] = kb;                             // lane o < 6 holds d bout[o] (other groups hold copies)
     inc[S::w5 + 0] = lG * hl;
     inc[S::w5 + 1] = lI * hl;
@@ -832,7 +842,7 @@ __device__ __forceinline__ R rhs_vjp(Edge &e, R (&gwh)[(NL > 1) ? NL - 1 : 1][kM
     inc[S::w1 + 6] = d * FFA;
     inc[S::w1 + 7] = d * GLP1;
     inc[S::w1 + 8] = d * tvns;
-    e.add_all(inc);
+    e.template add_all<S::count>(inc);
     const R w11 = e.W(S::w1 + 1), w12 = e.W(S::w1 + 2), w13 = e.W(S::w1 + 3), w14 = e.W(S::w1 + 4), w15 = e.W(S::w1 + 5),
             w16 = e.W(S::w1 + 6), w17 = e.W(S::w1 + 7);
     R p[6];

@@ -107,10 +107,8 @@ __global__ __launch_bounds__(WTREG ? 256 : 64 * kBwdWaves, (sizeof(R) == 4 && !W
     for (int l = 0; l < ((NL > 1) ? NL - 1 : 1); ++l)
 #pragma unroll
         for (int k = 0; k < kMaxH; ++k) gwh[l][k] = R(0);
-    R go[17];
-#pragma unroll
-    for (int i = 0; i < 17; ++i) go[i] = R(0);
     const bool use_gd = a.gd_mode != 0;
+    R go = R(0);                                  // lane p < 17: d/d(ode constant p), summed over this wave's trajectories
     R *rec = rowsT + 8 * kWave + (kEdgeLds<R> ? (size_t)(1 + kBwdWaves) * EdgeSlots<NL>::count * kWave : 0) +
              (size_t)wave * 2 * kSlot;
     // one record = (NL + 1) rows of 64 reals; each row is one (fp32) or two (fp64) 4-byte-per-lane DMA instructions
@@ -238,10 +236,7 @@ __global__ __launch_bounds__(WTREG ? 256 : 64 * kBwdWaves, (sizeof(R) == 4 && !W
         }
     }
     if constexpr (GODE) {
-        if (a.gode && lane == 0) {
-#pragma unroll
-            for (int i = 0; i < 17; ++i) atomic_add(a.gode + 17 * set + i, go[i]);
-        }
+        if (a.gode && lane < 17) atomic_add(a.gode + 17 * set + lane, go);
     }
 }
 
@@ -322,9 +317,7 @@ __global__ __launch_bounds__(256, 1) void rhs_bwd_kernel(const RhsArgs<R> a)
     for (int l = 0; l < ((NL > 1) ? NL - 1 : 1); ++l)
 #pragma unroll
         for (int k = 0; k < kMaxH; ++k) gwh[l][k] = R(0);
-    R go[17];
-#pragma unroll
-    for (int i = 0; i < 17; ++i) go[i] = R(0);
+    R go = R(0);
     for (int s = blockIdx.x * 4 + wave; s < a.B; s += gridDim.x * 4) {
         const R Y = (lane < 6) ? a.x[(size_t)s * 6 + lane] : R(0);
         const R kb = (lane < 6) ? a.gout[(size_t)s * 6 + lane] : R(0);
@@ -345,10 +338,7 @@ __global__ __launch_bounds__(256, 1) void rhs_bwd_kernel(const RhsArgs<R> a)
         edge_flush<R, NL>(E, a.gnn, a.H, lane);
     }
     if constexpr (GODE) {
-        if (a.gode && lane == 0) {
-#pragma unroll
-            for (int i = 0; i < 17; ++i) atomic_add(a.gode + i, go[i]);
-        }
+        if (a.gode && lane < 17) atomic_add(a.gode + lane, go);
     }
 }
 
