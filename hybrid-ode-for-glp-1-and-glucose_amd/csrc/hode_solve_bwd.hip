@@ -54,7 +54,7 @@ template <typename R, int NL> __host__ __device__ constexpr size_t bwd_lds_elems
 // WTREG = false: kBwdWaves (8) waves per workgroup, transposed matrices in LDS, 2 waves/SIMD.
 // WTREG = true (fp32): 4 waves per workgroup, transposed matrices in registers, 1 wave/SIMD, no LDS wait
 //         inside the 64-FMA loops.
-template <typename R, int NL, bool GODE, bool WTREG>
+template <typename R, int NL, bool GODE, bool WTREG, bool GD>
 __global__ __launch_bounds__(WTREG ? 256 : 64 * kBwdWaves, (sizeof(R) == 4 && !WTREG ? 2 : 1)) void solve_bwd_kernel(const AdjArgs<R> a, const int method)
 {
     constexpr int kWaves = WTREG ? 4 : kBwdWaves;
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(WTREG ? 256 : 64 * kBwdWaves, (sizeof(R) == 4 && !W
     for (int l = 0; l < ((NL > 1) ? NL - 1 : 1); ++l)
 #pragma unroll
         for (int k = 0; k < kMaxH; ++k) gwh[l][k] = R(0);
-    const bool use_gd = a.gd_mode != 0;
+    constexpr bool use_gd = GD;                   // Hill-term code (pow, log) only in the GD instantiation
     R go = R(0);                                  // lane p < 17: d/d(ode constant p), summed over this wave's trajectories
     R *rec = rowsT + 8 * kWave + (kEdgeLds<R> ? (size_t)(1 + kBwdWaves) * EdgeSlots<NL>::count * kWave : 0) +
              (size_t)wave * 2 * kSlot;
@@ -180,7 +180,8 @@ __global__ __launch_bounds__(WTREG ? 256 : 64 * kBwdWaves, (sizeof(R) == 4 && !W
                 const R ts = rfma((R)tab.c[s], h, tc);
                 const R al = (ts - t0) * inv_len;
                 const R gdv = rfma(al, dd, d0);
-                const R gde = use_gd ? gd_effect(o, gdv) : R(0);
+                R gde = R(0);
+                if constexpr (use_gd) gde = gd_effect(o, gdv);
                 const R Z = rhs_vjp<R, NL, GODE, false>(E, gwh, wtp, o, ts, Ys, rfma(al, dv, v0), gde, gdv, use_gd, lane, ac, kb,
                                                         go, nullptr);
                 ZZ = (grp == s) ? Z : ZZ;
@@ -240,7 +241,7 @@ __global__ __launch_bounds__(WTREG ? 256 : 64 * kBwdWaves, (sizeof(R) == 4 && !W
     }
 }
 
-template <typename R, int NL, bool GODE, bool WTREG> static int launch_bwd_k(hipStream_t s, const AdjArgs<R> &a, int method)
+template <typename R, int NL, bool GODE, bool WTREG, bool GD> static int launch_bwd_g(hipStream_t s, const AdjArgs<R> &a, int method)
 {
     constexpr int kW = WTREG ? 4 : kBwdWaves;
     const int per_set = a.B / a.n_sets;
@@ -250,11 +251,16 @@ template <typename R, int NL, bool GODE, bool WTREG> static int launch_bwd_k(hip
     if (blocks < 1) blocks = 1;
     const size_t lds = bwd_lds_elems<R, NL>() * sizeof(R);
     dim3 grid(blocks, a.n_sets), block(64 * kW);
-    auto kern = solve_bwd_kernel<R, NL, GODE, WTREG>;
+    auto kern = solve_bwd_kernel<R, NL, GODE, WTREG, GD>;
     if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return HODE_ELAUNCH;
     hipLaunchKernelGGL(kern, grid, block, lds, s, a, method);
     return hipGetLastError() == hipSuccess ? HODE_OK : HODE_ELAUNCH;
+}
+
+template <typename R, int NL, bool GODE, bool WTREG> static int launch_bwd_k(hipStream_t s, const AdjArgs<R> &a, int method)
+{
+    return a.gd_mode != 0 ? launch_bwd_g<R, NL, GODE, WTREG, true>(s, a, method) : launch_bwd_g<R, NL, GODE, WTREG, false>(s, a, method);
 }
 
 // fp32 default: transposed matrices in LDS, 2 waves/SIMD (measured 11.0 ms per 4096x241 adjoint).

@@ -21,7 +21,7 @@ template <typename R> struct Eps;
 template <> struct Eps<float> { static constexpr float v = 1.1920929e-7f; };
 template <> struct Eps<double> { static constexpr double v = 2.220446049250313e-16; };
 
-template <typename R, int NL, int METHOD, int LB, bool TAPE>
+template <typename R, int NL, int METHOD, int LB, bool TAPE, bool GD>
 __global__ __launch_bounds__(64, LB) void solve_fwd_kernel(const SolveArgs<R> a)
 {
     __shared__ R rows[8 * kWave];             // tableau coefficient rows (hode_device.h)
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(64, LB) void solve_fwd_kernel(const SolveArgs<R> a)
     // stage tape: [step][stage 0..5][NL activations + stage state][64 lanes]
     constexpr int kSlot = (NL + 1) * kWave;
     R *__restrict__ stg = TAPE ? a.tape_stage + (size_t)b * a.max_steps * 6 * kSlot : nullptr;
-    const bool use_gd = a.gd_mode != 0;
+    constexpr bool use_gd = GD;               // the Hill term (two pow calls) only exists in the GD instantiation
     const TableauData &tab = kTableau[METHOD];
 
     // state, replicated over the eight 8-lane groups: lane l holds y_{l&7}
@@ -98,7 +98,8 @@ __global__ __launch_bounds__(64, LB) void solve_fwd_kernel(const SolveArgs<R> a)
         // slot >= 0 (TAPE): also record the layer activations and the stage state for the adjoint
         auto f_at = [&](R ts, R Ys, int slot) -> R {
             const R al = (ts - t0) * inv_len;
-            const R gde = use_gd ? gd_effect(o, rfma(al, dd, d0)) : R(0);
+            R gde = R(0);
+            if constexpr (use_gd) gde = gd_effect(o, rfma(al, dd, d0));
             if constexpr (TAPE) {
                 MlpActs<R, NL> ac;
                 const R F = rhs_eval<R, NL, true>(W, o, ts, Ys, rfma(al, dm, m0), rfma(al, dv, v0), gde, lane, &ac);
@@ -223,17 +224,23 @@ __global__ __launch_bounds__(64, LB) void solve_fwd_kernel(const SolveArgs<R> a)
     }
 }
 
+template <typename R, int NL, int METHOD, bool TAPE, bool GD>
+static void launch_one(hipStream_t s, const SolveArgs<R> &a)
+{
+    constexpr int LB = (sizeof(R) == 4 ? 2 : 1);
+    hipLaunchKernelGGL((solve_fwd_kernel<R, NL, METHOD, LB, TAPE, GD>), dim3(a.B), dim3(64), 0, s, a);
+}
+
 template <typename R, int NL>
 static int launch_nl(hipStream_t s, const SolveArgs<R> &a, int method)
 {
-    dim3 grid(a.B), block(64);
-    constexpr int LB = (sizeof(R) == 4 ? 2 : 1);
+    const bool tape = a.tape != nullptr, gd = a.gd_mode != 0;
     if (method == HODE_METHOD_DP54) {
-        if (a.tape) hipLaunchKernelGGL((solve_fwd_kernel<R, NL, HODE_METHOD_DP54, LB, true>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((solve_fwd_kernel<R, NL, HODE_METHOD_DP54, LB, false>), grid, block, 0, s, a);
+        if (tape) { if (gd) launch_one<R, NL, HODE_METHOD_DP54, true, true>(s, a); else launch_one<R, NL, HODE_METHOD_DP54, true, false>(s, a); }
+        else { if (gd) launch_one<R, NL, HODE_METHOD_DP54, false, true>(s, a); else launch_one<R, NL, HODE_METHOD_DP54, false, false>(s, a); }
     } else {
-        if (a.tape) hipLaunchKernelGGL((solve_fwd_kernel<R, NL, HODE_METHOD_RK4, LB, true>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((solve_fwd_kernel<R, NL, HODE_METHOD_RK4, LB, false>), grid, block, 0, s, a);
+        if (tape) { if (gd) launch_one<R, NL, HODE_METHOD_RK4, true, true>(s, a); else launch_one<R, NL, HODE_METHOD_RK4, true, false>(s, a); }
+        else { if (gd) launch_one<R, NL, HODE_METHOD_RK4, false, true>(s, a); else launch_one<R, NL, HODE_METHOD_RK4, false, false>(s, a); }
     }
     return hipGetLastError() == hipSuccess ? HODE_OK : HODE_ELAUNCH;
 }
