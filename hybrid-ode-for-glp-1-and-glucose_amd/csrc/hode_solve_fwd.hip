@@ -25,6 +25,7 @@ template <typename R, int NL, int METHOD, int LB, bool TAPE, bool GD>
 __global__ __launch_bounds__(64, LB) void solve_fwd_kernel(const SolveArgs<R> a)
 {
     __shared__ R rows[8 * kWave];             // tableau coefficient rows (hode_device.h)
+    __shared__ R cvec[8];                     // tableau nodes c[s] as reals
     __shared__ R ybuf[kWave + 8];             // output staging: rows of 6 reals are gathered into 256-byte stores
     __shared__ R wstage[(sizeof(R) == 4) ? kStageElems : 1];   // weight-row permutation scratch (prologue only)
     const int lane = threadIdx.x;
@@ -34,6 +35,7 @@ __global__ __launch_bounds__(64, LB) void solve_fwd_kernel(const SolveArgs<R> a)
     const int set = b / (a.B / a.n_sets);
 
     tableau_rows_store<R>(rows, METHOD, lane, 64);
+    if (lane < 8) cvec[lane] = (R)kTableau[METHOD].c[lane];
     MlpRegs<R, NL> W;
     mlp_load<R, NL>(W, a.nn_p + (size_t)set * a.P, a.H, lane, wstage);
     OdeP<R> o;
@@ -170,17 +172,22 @@ __global__ __launch_bounds__(64, LB) void solve_fwd_kernel(const SolveArgs<R> a)
                     tn = first_lane(tn);
                     KK = (grp == 0) ? KK : R(0);          // drop stale stages (0 * NaN would poison the sums)
                     R Ys = Y, F = R(0);
+                    // the coefficient row and node of stage s+1 are fetched from LDS BEFORE the RHS of stage s,
+                    // so the LDS latency hides behind the MLP instead of opening every stage
+                    R coef = rows[1 * kWave + lane], cs = cvec[1];
 #pragma unroll 1
                     for (int s = 1; s <= 6; ++s) {        // stages 2..6 and the FSAL stage (row 6 = 5th-order weights)
-                        Ys = rfma(h, group_sum8(rows[s * kWave + lane] * KK), Y);
-                        const R ts = (s >= 5) ? tn : rfma((R)tab.c[s], h, tc);
+                        Ys = rfma(h, group_sum8(coef * KK), Y);
+                        const R ts = (s >= 5) ? tn : rfma(cs, h, tc);
+                        coef = rows[(s + 1) * kWave + lane];   // s = 6 fetches row 7 = error weights
+                        cs = cvec[(s + 1) & 7];
                         // stage s of this step; the FSAL stage (s == 6) is stage 0 of the NEXT step
                         F = f_at(ts, Ys, (s < 6) ? ns * 6 + s : (ns + 1) * 6);
                         KK = (grp == s) ? F : KK;
                     }
                     const R Yn = Ys;                      // 5th-order solution
                     nf += 6;
-                    const R err = h * group_sum8(rows[7 * kWave + lane] * KK);
+                    const R err = h * group_sum8(coef * KK);
                     const R ymax = rabs(Y) > rabs(Yn) ? rabs(Y) : rabs(Yn);
                     const R qe = (c8 < 6) ? err / (a.atol + ymax * a.rtol) : R(0);
                     float en = sqrtf((float)first_lane(oct_allsum(qe * qe)) / 6.0f);
