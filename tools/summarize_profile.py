@@ -44,11 +44,13 @@ traffic = {}
 for k, d in pmc.items():
     if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
         d["hbm_bytes_per_launch_corrected"] = (2 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024
-        if "solve_fwd" in k and "false>" in k:          # forward-only instantiation (no tape)
+        targs = [a.strip() for a in k[k.index("<") + 1:k.rindex(">")].split(",")] if "<" in k else []
+        tape_inst = len(targs) >= 5 and targs[4] == "true"          # solve_fwd_kernel<R, NL, METHOD, LB, TAPE, GD>
+        if "solve_fwd" in k and not tape_inst:          # forward-only instantiation (no tape)
             traffic["solve_fwd_hbm_bytes_per_launch"] = d["hbm_bytes_per_launch_corrected"]
             traffic["solve_fwd_fetch_kib_raw"] = d["FETCH_SIZE"]
             traffic["solve_fwd_write_kib_raw"] = d["WRITE_SIZE"]
-        if "solve_fwd" in k and "true>" in k:           # training instantiation: also writes the stage tape
+        if "solve_fwd" in k and tape_inst:              # training instantiation: also writes the stage tape
             traffic["solve_fwd_tape_hbm_bytes_per_launch"] = d["hbm_bytes_per_launch_corrected"]
         if "solve_bwd" in k:
             traffic["solve_bwd_hbm_bytes_per_launch"] = d["hbm_bytes_per_launch_corrected"]
