@@ -450,3 +450,50 @@ def test_full_size_properties(hode, g0):
     _, g1, _ = hode.solve_bwd(h1, gy[:1000])
     _, g2, _ = hode.solve_bwd(h2, gy[1000:])
     assert relnorm((g1 + g2).cpu().numpy(), gall.cpu().numpy()) < 1e-5
+
+
+def test_training_step_is_graph_capturable(hode, golden_dir, g0):
+    """include/hode.h promises: every entry point only enqueues work on the given stream (no allocation, no
+    synchronisation), so a whole training step -- solve with tape, fused MSE, adjoint, clip+Adam -- can be
+    captured into a hipGraph and replayed.  Replays must reproduce the eager step."""
+    g = np.load(os.path.join(golden_dir, "g4_t61_rand.npz"))
+    dt = torch.float32
+    x0, t, meal, tv = dev(g["x0"], dt), dev(g["t"], dt), dev(g["meal"], dt), dev(g["tvns"], dt)
+    obs = dev(g["y_rk45_tight"], dt) + 0.05
+    ode = dev(g0["ode"], dt)
+    n_el = float(obs.numel())
+
+    def make_state():
+        p = dev(g0["nn"], dt).clone()
+        return p, torch.zeros_like(p), torch.zeros_like(p), torch.zeros(2, device="cuda")
+
+    def step(p, m, v, scratch, k):
+        sol = hode.solve_fwd(x0, t, meal, tv, None, ode, p, 64, 4, want_tape=True)
+        loss, gy = hode.mse_fwd_bwd(sol.y, obs, 1.0 / n_el)
+        _, gnn, _ = hode.solve_bwd(sol, gy)
+        hode.adam_step(p, gnn, m, v, 1e-3, step=k, max_norm=5.0, scratch=scratch)
+        return loss
+
+    # eager reference: two steps
+    pe, me, ve, se = make_state()
+    for k in (1, 2):
+        step(pe, me, ve, se, k)
+    torch.cuda.synchronize()
+    # captured: one graph per Adam step index (the bias correction is a launch argument)
+    pg, mg, vg, sg = make_state()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        step(pg.clone(), mg.clone(), vg.clone(), sg.clone(), 1)          # warm-up outside capture
+    torch.cuda.current_stream().wait_stream(side)
+    graphs = []
+    for k in (1, 2):
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            step(pg, mg, vg, sg, k)
+        graphs.append(gr)
+    pg.copy_(dev(g0["nn"], dt)); mg.zero_(); vg.zero_()                  # capture does not execute: reset and replay
+    for gr in graphs:
+        gr.replay()
+    torch.cuda.synchronize()
+    assert float((pg - pe).abs().max()) < 1e-6 and float((pg - dev(g0["nn"], dt)).abs().max()) > 0
