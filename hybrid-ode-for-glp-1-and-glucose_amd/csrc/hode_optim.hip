@@ -90,8 +90,10 @@ __global__ __launch_bounds__(256) void mse_kernel(int64_t n4, int64_t n, const f
 int launch_mse(hipStream_t s, int64_t n, const float *y, const float *obs, float scale, double *loss, float *gy)
 {
     if (n <= 0) return HODE_OK;
-    const int64_t n4 = n / 4;
-    int blocks = (int)((n4 + 255) / 256);
+    // the 16-byte path needs 16-byte aligned pointers; anything else takes the scalar tail loop
+    const bool aligned = (((uintptr_t)y | (uintptr_t)obs | (uintptr_t)gy) & 15) == 0;
+    const int64_t n4 = aligned ? n / 4 : 0;
+    int blocks = (int)(((aligned ? n4 : n) + 255) / 256);
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(mse_kernel, dim3(blocks), dim3(256), 0, s, n4, n, y, obs, scale, loss, gy);

@@ -127,6 +127,7 @@ __global__ __launch_bounds__(64, LB) void solve_fwd_kernel(const SolveArgs<R> a)
         R tc = t0;
 
         if constexpr (METHOD == HODE_METHOD_RK4) {
+            if (ns >= a.max_steps) { st = HODE_ST_MAXSTEPS; break; }     // budget < T-1: report, never overrun the tape
             const R hh = len;
             KK = R(0);
 #pragma unroll 1
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(64, LB) void solve_fwd_kernel(const SolveArgs<R> a)
                 const R F = f_at(rfma((R)tab.c[s], hh, t0), Ys, ns * 6 + s);
                 KK = (grp == s) ? F : KK;
             }
-            if (ns < a.max_steps) tape_put(t0, hh);
+            tape_put(t0, hh);
             Y = rfma(hh, group_sum8(rows[7 * kWave + lane] * KK), Y);
             nf += 4;
             ns += 1;

@@ -497,3 +497,31 @@ def test_training_step_is_graph_capturable(hode, golden_dir, g0):
         gr.replay()
     torch.cuda.synchronize()
     assert float((pg - pe).abs().max()) < 1e-6 and float((pg - dev(g0["nn"], dt)).abs().max()) > 0
+
+
+def test_mse_unaligned_and_rk4_budget(hode, g0):
+    """C-ABI robustness: mse on 4-byte-aligned (not 16-byte-aligned) views takes the scalar path; an RK4 solve whose
+    step budget is smaller than T-1 reports status 1 instead of overrunning the tape."""
+    torch.manual_seed(2)
+    base_y, base_o = torch.randn(1001, device="cuda"), torch.randn(1001, device="cuda")
+    y, o = base_y[1:], base_o[1:]                                    # data_ptr() % 16 == 4
+    assert y.data_ptr() % 16 != 0
+    loss = torch.zeros(1, dtype=torch.float64, device="cuda")
+    gy = torch.empty(1000, device="cuda")
+    import ctypes as C
+    rc = hode.load().hode_mse_fwd_bwd_f32(C.c_void_p(torch.cuda.current_stream().cuda_stream), C.c_int64(1000),
+                                          C.c_void_p(y.data_ptr()), C.c_void_p(o.data_ptr()), C.c_float(0.5),
+                                          C.c_void_p(loss.data_ptr()), C.c_void_p(gy.data_ptr()))
+    assert rc == 0
+    assert abs(float(loss) - float(((y - o).double() ** 2).sum())) < 1e-6 * float(loss)
+    assert torch.allclose(gy, (y - o), rtol=1e-6, atol=1e-7)
+    dt = torch.float64
+    x0 = dev([[5, 60, 80, 10, 0, 1.0]], dt)
+    t = dev(np.linspace(0, 1, 11), dt)
+    s = hode.solve_fwd(x0, t, None, None, None, dev(g0["ode"], dt), dev(g0["nn"], dt), 64, 4, method=hode.METHOD_RK4,
+                       max_steps=4, want_tape=True)
+    assert int(s.status[0]) == 1 and int(s.nsteps[0]) == 4
+    y = s.y.cpu().numpy()
+    assert np.all(y[0, 5:] == 0) and np.all(y[0, :5, 0] != 0)
+    gx0, gnn, _ = hode.solve_bwd(s, torch.ones_like(s.y))
+    assert torch.isfinite(gx0).all() and torch.isfinite(gnn).all()
