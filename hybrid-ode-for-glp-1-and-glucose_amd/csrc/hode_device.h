@@ -196,7 +196,8 @@ template <typename R> __device__ __forceinline__ void tableau_rows_store(R *rows
         rows[i] = (R)v;
     }
 }
-// transposed rows for the adjoint: rowsT[s][lane] = A[lane>>3][s] (only stages < S); row 7 = 1 for stages < S
+// transposed rows for the adjoint: rowsT[s][lane] = A[lane>>3][s] (only stages < S); row 7 = 1 for stages < S;
+// row 6 carries the solution weights bw[0..7] (lanes 0..7) and the nodes c[0..7] (lanes 8..15) as reals
 template <typename R> __device__ __forceinline__ void tableau_rowsT_store(R *rows, int method, int tid, int nthreads)
 {
     const int S = kTableau[method].S;
@@ -204,6 +205,7 @@ template <typename R> __device__ __forceinline__ void tableau_rowsT_store(R *row
         const int s = i >> 6, l = i & 63, j = l >> 3;
         double v = (j < S && s < S) ? kTableau[method].A[j][s] : 0.0;
         if (s == 7) v = (j < S) ? 1.0 : 0.0;
+        if (s == 6) v = (l < 8) ? kTableau[method].bw[l] : (l < 16) ? kTableau[method].c[l - 8] : 0.0;   // scalars as reals
         rows[i] = (R)v;
     }
 }

@@ -176,8 +176,10 @@ __global__ __launch_bounds__(WTREG ? 256 : 64 * kBwdWaves, (sizeof(R) == 4 && !W
                 for (int l = 0; l < NL; ++l) ac.h[l] = rec[cur * kSlot + l * kWave + lane];
                 const R Ys = rec[cur * kSlot + NL * kWave + lane];
                 cur ^= 1;
-                const R kb = h * rfma((R)tab.bw[s], lam, group_sum8(rowsT[s * kWave + lane] * ZZ));
-                const R ts = rfma((R)tab.c[s], h, tc);
+                // tableau scalars come from LDS with the record (one wait), not from constant memory (an s_load + wait per stage)
+                const R bw_s = rowsT[6 * kWave + s], c_s = rowsT[6 * kWave + 8 + s];
+                const R kb = h * rfma(bw_s, lam, group_sum8(rowsT[s * kWave + lane] * ZZ));
+                const R ts = rfma(c_s, h, tc);
                 const R al = (ts - t0) * inv_len;
                 const R gdv = rfma(al, dd, d0);
                 R gde = R(0);
