@@ -234,7 +234,7 @@ template <typename R> __device__ __forceinline__ int wcol(int r, int lane)
 
 // Row stride of the LDS staging area used to permute a weight row into rotating-operand order.
 constexpr int kStageStride = kMaxH + 1;
-constexpr int kStageElems = kMaxH * kStageStride;
+constexpr int kStageElems = (kMaxH / 2) * kStageStride;      // two passes of 32 lanes: 8.3 KB instead of 16.6 KB per wave
 
 // Load one parameter set into registers.  `stage` = wave-private LDS scratch of kStageElems reals (fp32 only;
 // may be nullptr for fp64): every lane reads its weight row with coalesced 16-byte loads, drops it into LDS
@@ -255,22 +255,32 @@ __device__ __forceinline__ void mlp_load(MlpRegs<R, NL> &W, const R *__restrict_
     for (int l = 0; l < NL - 1; ++l) {
         const R *row = p + (size_t)j * H;
         if constexpr (sizeof(R) == 4) {
-            R *mine = stage + lane * kStageStride;
-            if (H == kMaxH) {
-                const float4 *r4 = reinterpret_cast<const float4 *>(row);
+            // two passes (lanes 0..31, then 32..63) keep the scratch at 8.3 KB per wave, so that LDS does not cap
+            // the residency of the one-wave workgroups
+            R *mine = stage + (lane & 31) * kStageStride;
 #pragma unroll
-                for (int k = 0; k < kMaxH / 4; ++k) {
-                    const float4 v = r4[k];
-                    mine[4 * k + 0] = v.x; mine[4 * k + 1] = v.y; mine[4 * k + 2] = v.z; mine[4 * k + 3] = v.w;
-                }
-            } else {
+            for (int half = 0; half < 2; ++half) {
+                const bool active = (lane >> 5) == half;
+                if (active) {
+                    if (H == kMaxH) {
+                        const float4 *r4 = reinterpret_cast<const float4 *>(row);
+#pragma unroll
+                        for (int k = 0; k < kMaxH / 4; ++k) {
+                            const float4 v = r4[k];
+                            mine[4 * k + 0] = v.x; mine[4 * k + 1] = v.y; mine[4 * k + 2] = v.z; mine[4 * k + 3] = v.w;
+                        }
+                    } else {
 #pragma unroll 8
-                for (int k = 0; k < kMaxH; ++k) mine[k] = ((k < H) ? live : R(0)) * row[(k < H) ? k : H - 1];
-            }
-            __builtin_amdgcn_wave_barrier();
+                        for (int k = 0; k < kMaxH; ++k) mine[k] = ((k < H) ? live : R(0)) * row[(k < H) ? k : H - 1];
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (active) {
 #pragma unroll
-            for (int r = 0; r < kMaxH; ++r) W.wh[l][r] = mine[wcol<R>(r, lane)];      // own row, rotated order
-            __builtin_amdgcn_wave_barrier();
+                    for (int r = 0; r < kMaxH; ++r) W.wh[l][r] = mine[wcol<R>(r, lane)];      // own row, rotated order
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
         } else {
             (void)stage;
             if (H == kMaxH) {

@@ -235,7 +235,8 @@ __global__ __launch_bounds__(64, LB) void solve_fwd_kernel(const SolveArgs<R> a)
 template <typename R, int NL, int METHOD, bool TAPE, bool GD>
 static void launch_one(hipStream_t s, const SolveArgs<R> &a)
 {
-    constexpr int LB = (sizeof(R) == 4 ? 2 : 1);
+    // waves per SIMD the register budget allows: 211 weight registers for 3 hidden matrices -> 2; fewer layers -> more
+    constexpr int LB = (sizeof(R) == 4) ? (NL >= 3 ? 2 : (NL == 2 ? 3 : 4)) : 1;
     hipLaunchKernelGGL((solve_fwd_kernel<R, NL, METHOD, LB, TAPE, GD>), dim3(a.B), dim3(64), 0, s, a);
 }
 
