@@ -3,23 +3,23 @@
 // No reference counterpart: the reference detaches the solve (models/hybrid_ode_nn.py:186,
 // 234-237, 248).  north_star asks for adjoint backprop, so this kernel
 // differentiates the discrete scheme the forward kernel ran ("discretise-then-differentiate"):
-// it walks the tape of accepted steps backwards, recomputes the Runge-Kutta stages of each step
-// and pulls the cotangent through them.  Step sizes are treated as constants.  (Stages are replayed
-// from the stage tape, see below.)
+// it walks the tape of accepted steps backwards and pulls the cotangent through the Runge-Kutta stages
+// of each step.  Step sizes are treated as constants.
 // CPU restatement: oracle/hode_oracle_impl.h (hode_oracle_solve_bwd).
 //
 // Mapping: one trajectory per wavefront, one hidden unit per lane (see hode_device.h).
 //   * the forward recorded, for every stage of every accepted step, the layer activations and the
-//     stage state on the "stage tape" in HBM (7.7 KB per step in fp32): the adjoint re-reads them
-//     (coalesced 256-byte rows, prefetched one stage ahead) instead of recomputing the forward --
-//     a memory-for-compute trade that 288 GB / 8 TB/s of HBM3E make cheap;
-//   * lane j keeps row j of the gradient accumulators in VGPRs (211 registers in fp32) plus the
-//     first/last layer weights (15): 2 waves per SIMD;
+//     stage state on the "stage tape" in HBM (7.7 KB per step in fp32): the adjoint streams them back
+//     by LDS-DMA (global_load ... lds, one stage ahead, double buffered) instead of recomputing the
+//     forward -- a memory-for-compute trade that 288 GB / 8 TB/s of HBM3E make cheap;
+//   * lane j keeps row j of the three hidden-matrix gradient accumulators in VGPRs (192 registers in
+//     fp32): 2 waves per SIMD.  First/last-layer weights and their accumulators live in LDS tables;
 //   * dW_l[j][:] += delta_l[j] * h_{l-1}[:]  is 64 v_fmac_f32_dpp (rotating-operand form);
 //   * delta_{l-1} = W_l^T delta_l reads the transposed matrices from an LDS image shared by the
-//     8 waves of the workgroup (one 16-byte read per 4 FMAs, again with DPP row_ror operands);
-//   * a wave loops over several trajectories and keeps accumulating, so the cross-trajectory
-//     reduction costs one atomic flush per wave at the end (13.5k atomics per wave).
+//     8 waves of the workgroup (one 16-byte read per 4 FMAs, again with DPP row_ror operands); the
+//     outer-product FMAs sit between the issue and the use of every group of reads;
+//   * a wave loops over several trajectories and keeps accumulating; at the end the 8 waves of a
+//     workgroup reduce through LDS and flush coalesced atomics (12 k per workgroup).
 #include "hode_device.h"
 #include "hode_kernels.h"
 #include <type_traits>
@@ -49,8 +49,7 @@ template <typename R, int NL> __host__ __device__ constexpr size_t bwd_lds_elems
 }
 
 // The adjoint reads, for every stage of every accepted step, what the forward recorded on the stage
-// tape (layer activations + stage state): it never recomputes the forward.  Registers therefore hold
-// only the gradient accumulators (211) + the first/last layer weights (15): 2 waves per SIMD in fp32.
+// tape (layer activations + stage state): it never recomputes the forward.
 // WTREG = false: kBwdWaves (8) waves per workgroup, transposed matrices in LDS, 2 waves/SIMD.
 // WTREG = true (fp32): 4 waves per workgroup, transposed matrices in registers, 1 wave/SIMD, no LDS wait
 //         inside the 64-FMA loops.
