@@ -338,3 +338,22 @@ def test_elbo_value_and_reparameterised_gradient(M):
             p[idx] += h
         fd = (ep - em) / (2 * h)
         assert abs(fd - g_an) <= 5e-2 * max(abs(fd), 1e-2 * float(vp.means[name].grad.abs().max()) + 1e-9), (name, fd, g_an)
+
+
+def test_sobol_style_one_patient_per_parameter_set(M, golden_dir):
+    """plots/plot_all.py:171-196 runs 16 384 single-patient forwards, each after setattr-ing ODE constants.
+    Here: S parameter sets x 1 patient in ONE launch (n_sets == B), equal to S separate calls."""
+    g = np.load(os.path.join(golden_dir, "g4_t61_pulses.npz"))
+    m = load_model(M, golden_dir, "cuda")
+    x0 = torch.tensor(g["x0"][0]).cuda()
+    t = torch.tensor(g["t"]).cuda()
+    ext = {"meal": torch.tensor(g["meal"][:1]).cuda(), "tVNS": torch.tensor(g["tvns"][:1]).cuda()}
+    rng = np.random.default_rng(0)
+    sets = [{"ode_k_L": torch.tensor(0.02 * (0.5 + rng.random())), "ode_V_max": torch.tensor(9.0 * (0.5 + rng.random())),
+             "ode_E_max": torch.tensor(0.1 * (0.5 + rng.random()))} for _ in range(37)]
+    with torch.no_grad():
+        ys = m.forward_param_sets(sets, x0, t, ext)                       # [37, T, 6]
+        one = torch.stack([m.forward_with_params(d, x0, t, ext) for d in sets[:5]])
+    assert tuple(ys.shape) == (37, g["t"].shape[0], 6)
+    assert torch.equal(ys[:5], one)
+    assert float((ys[0] - ys[1]).abs().max()) > 1e-3
