@@ -357,3 +357,38 @@ def test_sobol_style_one_patient_per_parameter_set(M, golden_dir):
     assert tuple(ys.shape) == (37, g["t"].shape[0], 6)
     assert torch.equal(ys[:5], one)
     assert float((ys[0] - ys[1]).abs().max()) > 1e-3
+
+
+def test_fused_train_step_matches_class_path(M, golden_dir):
+    """The fused pipeline of bench.py / hode.train (solve with tape -> fused MSE -> adjoint -> clip+Adam kernels)
+    makes the same parameter update as the drop-in class path (HybridODENN.loss(data term) -> autograd ->
+    clip_grad_norm_ -> torch.optim.Adam), and the loss goes down over a few steps."""
+    import hode
+    g = np.load(os.path.join(golden_dir, "g4_t61_rand.npz"))
+    m = load_model(M, golden_dir, "cuda")
+    x0, t = torch.tensor(g["x0"]).cuda(), torch.tensor(g["t"]).cuda()
+    meal, tv = torch.tensor(g["meal"]).cuda(), torch.tensor(g["tvns"]).cuda()
+    obs = torch.tensor(g["y_rk45_tight"]).cuda() * 1.02
+    batch = {"initial_state": x0, "observations": obs, "time_points": t, "external_inputs": {"meal": meal, "tVNS": tv}}
+    # class path
+    opt = torch.optim.Adam(m.nn_residual.parameters(), lr=1e-3)
+    loss_c = m.loss(batch, lambda1=0.0, lambda2=0.0, use_physics_loss=False)
+    opt.zero_grad()
+    loss_c.backward()
+    torch.nn.utils.clip_grad_norm_(m.nn_residual.parameters(), 5.0)
+    p_before = m.nn_residual.flat_parameters().detach().clone()
+    opt.step()
+    p_class = m.nn_residual.flat_parameters().detach()
+    # fused path from the same starting point
+    state = hode.train.TrainState(p_before.clone())
+    ode = m.ode_core.param_vector(device="cuda")
+    n_el = obs.numel()
+
+    def compute(p):
+        ls, gnn, gode, _ = hode.train.hip_loss_and_grads(p, ode, x0, t, meal, tv, obs, 64, 4, n_el, state=state)
+        return ls, gnn, gode, n_el
+    loss_f = hode.train.train_step(state, compute, lr=1e-3, max_norm=5.0)
+    assert abs(float(loss_f) - float(loss_c)) < 1e-5 * float(loss_c)
+    assert float((state.p - p_class).abs().max()) < 2e-6
+    losses = [float(loss_f)] + [float(hode.train.train_step(state, compute, lr=1e-3, max_norm=5.0)) for _ in range(8)]
+    assert losses[-1] < losses[0]
