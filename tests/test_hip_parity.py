@@ -525,3 +525,21 @@ def test_mse_unaligned_and_rk4_budget(hode, g0):
     assert np.all(y[0, 5:] == 0) and np.all(y[0, :5, 0] != 0)
     gx0, gnn, _ = hode.solve_bwd(s, torch.ones_like(s.y))
     assert torch.isfinite(gx0).all() and torch.isfinite(gnn).all()
+
+
+def test_largest_baseline_cohort_on_one_gpu(hode):
+    """BASELINE config 4 is a 65 536-patient cohort (8 192 per GPU on 8 GPUs).  The whole cohort also fits one GPU:
+    every trajectory succeeds and the per-GPU shards of the 8-rank split reproduce the corresponding rows bitwise
+    (patient sharding changes nothing numerically: there is no cross-trajectory coupling)."""
+    import bench
+    B = 65536
+    x0, t, meal, tv = (v.cuda() for v in bench.synth_cohort(B, 2024))
+    nn, ode = bench.synth_weights(0).cuda(), bench.ODE_DEFAULT.cuda()
+    full = hode.solve_fwd(x0, t, meal, tv, None, ode, nn, 64, 4)
+    assert int(full.status.max()) == 0 and int(full.nsteps.min()) >= 240
+    assert torch.isfinite(full.y).all()
+    for rank in (0, 5, 7):
+        lo, hi = hode.train.shard_bounds(B, rank, 8)
+        assert hi - lo == 8192
+        shard = hode.solve_fwd(x0[lo:hi], t, meal[lo:hi], tv[lo:hi], None, ode, nn, 64, 4)
+        assert torch.equal(shard.y, full.y[lo:hi])
