@@ -2,6 +2,8 @@
 // Plain pointers and sizes only; argument validation happens here, on the host, BEFORE any
 // launch: a kernel is never started on shapes it was not compiled for.
 #include "hode_kernels.h"
+#include <math.h>
+#include <string.h>
 #include "hode_device.h"
 
 using namespace hode;
@@ -185,6 +187,81 @@ int hode_selftest_xlane(void *stream, int32_t *out)
 {
     if (!out) return HODE_EINVAL;
     return launch_selftest((hipStream_t)stream, out);
+}
+
+// ---- data side -----------------------------------------------------------------------------------------------
+int hode_4gi_default_params(int patient_type, double *par)
+{
+    if (!par || (patient_type != HODE_4GI_T2DM && patient_type != HODE_4GI_HV)) return HODE_EINVAL;
+    const bool hv = patient_type == HODE_4GI_HV;
+    // data/generate4GI.py:15-64, in the order of HODE_4GI_NPAR
+    const double v[HODE_4GI_NPAR] = {hv ? 5.36 : 1.72, hv ? 0.072 : 0.0256, 26.5, 9.33, 8.56, 73.2, 6.09, exp(-0.159),
+                                     16.0, exp(7.97), exp(4.91), 453.2, 64.6, 86.8, 9.21, 49.4, 22.8, 2.46, exp(2.37),
+                                     exp(3.29), 1.79, 6.73, exp(4.59), 0.0102, 0.0343, 0.00329};
+    for (int i = 0; i < HODE_4GI_NPAR; ++i) par[i] = v[i];
+    return HODE_OK;
+}
+
+static int fourgi_params(int patient_type, const double *par_host, FourGIPar *out)
+{
+    double v[HODE_4GI_NPAR];
+    if (patient_type != HODE_4GI_T2DM && patient_type != HODE_4GI_HV) return HODE_EINVAL;
+    if (par_host)
+        for (int i = 0; i < HODE_4GI_NPAR; ++i) v[i] = par_host[i];
+    else
+        hode_4gi_default_params(patient_type, v);
+    memcpy(out, v, sizeof v);
+    return HODE_OK;
+}
+
+int hode_4gi_generate_f64(void *stream, int B, int T, double interval_min, int patient_type, const double *par_host,
+                          const double *bsl, int n_meals, const double *meal_time, const double *meal_size,
+                          int meals_per_subject, const double *z, double noise_cv, int64_t subject0, double rtol,
+                          double atol, int max_steps, double *table, int32_t *status)
+{
+    if (B < 0 || T < 1 || n_meals < 0 || max_steps < 1) return HODE_EINVAL;
+    if (!(interval_min > 0.0) || !(rtol > 0.0) || !(atol >= 0.0)) return HODE_EINVAL;
+    if (B == 0) return HODE_OK;
+    if (!bsl || !table || (n_meals > 0 && (!meal_time || !meal_size))) return HODE_EINVAL;
+    GenArgs a{};
+    if (int rc = fourgi_params(patient_type, par_host, &a.par)) return rc;
+    a.B = B; a.T = T; a.hv = patient_type == HODE_4GI_HV; a.n_meals = n_meals; a.meals_per_subject = meals_per_subject != 0;
+    a.max_steps = max_steps; a.subject0 = subject0; a.interval_min = interval_min; a.rtol = rtol; a.atol = atol;
+    a.noise_cv = noise_cv; a.bsl = bsl; a.meal_time = meal_time; a.meal_size = meal_size; a.z = z; a.table = table;
+    a.status = status;
+    return launch_4gi_generate((hipStream_t)stream, a);
+}
+
+int hode_4gi_rhs_f64(void *stream, int B, int patient_type, const double *par_host, const double *bsl, const double *y,
+                     const double *meal, double *d)
+{
+    if (B < 0) return HODE_EINVAL;
+    if (B == 0) return HODE_OK;
+    if (!bsl || !y || !meal || !d) return HODE_EINVAL;
+    FourGIPar p;
+    if (int rc = fourgi_params(patient_type, par_host, &p)) return rc;
+    return launch_4gi_rhs((hipStream_t)stream, B, patient_type == HODE_4GI_HV, p, bsl, y, meal, d);
+}
+
+int hode_4gi_windows_f32(void *stream, const double *table, int ncols, int col_time, double time_div, int col_glucose,
+                         int col_insulin, int col_glucagon, int col_glp1, int col_ge, int col_ffa, int col_meal,
+                         int col_tvns, const int64_t *row0, int64_t N, int64_t S, int normalize, float *states,
+                         float *meal, float *tvns, float *time, double *mean_std, void *scratch)
+{
+    if (N < 0 || S < 1 || ncols < 1 || !mean_std || !(time_div != 0.0)) return HODE_EINVAL;
+    const int need[5] = {col_time, col_glucose, col_insulin, col_glucagon, col_glp1};
+    for (int c : need)
+        if (c < 0 || c >= ncols) return HODE_EINVAL;
+    const int opt[4] = {col_ge, col_ffa, col_meal, col_tvns};
+    for (int c : opt)
+        if (c < -1 || c >= ncols) return HODE_EINVAL;
+    if (N > 0 && (!table || !row0 || !states || !meal || !tvns || !time || !scratch)) return HODE_EINVAL;
+    WinArgs a{};
+    a.table = table; a.ncols = ncols; a.col_time = col_time; a.col_meal = col_meal; a.col_tvns = col_tvns;
+    a.col_state[0] = col_glucose; a.col_state[1] = col_insulin; a.col_state[2] = col_glucagon; a.col_state[3] = col_glp1;
+    a.col_state[4] = col_ge; a.col_state[5] = col_ffa;
+    a.time_div = time_div; a.row0 = row0; a.N = N; a.S = S; a.states = states; a.meal = meal; a.tvns = tvns; a.time = time;
+    return launch_4gi_windows((hipStream_t)stream, a, normalize, mean_std, scratch);
 }
 
 }  // extern "C"

@@ -1,0 +1,373 @@
+// hode_datagen.hip -- the data side of the hot path, on the device:
+//
+//   K7  fourgi_generate_kernel   4GI (8-state) cohort simulator + measurement noise + 9-column table
+//                                replaces FourGIModel.simulate / generate_dataset (reference data/generate4GI.py:73-271:
+//                                one scipy.odeint call per subject per 5-minute interval, ~6 ms each)
+//   K8  win_* kernels            sliding windows + z-scoring of a table into fp32 training batches
+//                                replaces GlucoseDataset (reference train/train_hybrid.py:43-155: pandas groupby +
+//                                per-window numpy copies)
+//
+// K7 is a pure-ODE path (no MLP): ONE SUBJECT PER LANE (north_star's mapping), fp64, adaptive DP5(4) per lane with
+// free-running lanes (a lane does not wait for its neighbours at grid points).  ~1.2 kflop per RHS (three pow), 72 B
+// written per grid point: latency/VALU-bound, no LDS, no cross-lane traffic.  K8 is HBM-bound streaming: the table is
+// read three times (mean, centred second moment, emit -- the two-pass variance of numpy.std), outputs are written once,
+// coalesced.  Reductions are deterministic (fixed block partials, fixed-order final sum), so the same table always
+// gives the same batches.
+#include "hode_kernels.h"
+
+namespace hode {
+
+// Dormand-Prince 5(4): rows 1..5 = stage coefficients, row 6 = 5th-order weights (the 7th stage is evaluated at y_new)
+__constant__ double kDP[7][6] = {
+    {0, 0, 0, 0, 0, 0},
+    {1.0 / 5, 0, 0, 0, 0, 0},
+    {3.0 / 40, 9.0 / 40, 0, 0, 0, 0},
+    {44.0 / 45, -56.0 / 15, 32.0 / 9, 0, 0, 0},
+    {19372.0 / 6561, -25360.0 / 2187, 64448.0 / 6561, -212.0 / 729, 0, 0},
+    {9017.0 / 3168, -355.0 / 33, 46732.0 / 5247, 49.0 / 176, -5103.0 / 18656, 0},
+    {35.0 / 384, 0, 500.0 / 1113, 125.0 / 192, -2187.0 / 6784, 11.0 / 84}};
+__constant__ double kDPE[7] = {-71.0 / 57600, 0, 71.0 / 16695, -71.0 / 1920, 17253.0 / 339200, -22.0 / 525, 1.0 / 40};
+
+// per-subject constants of generate4GI.py:94-116 (they depend on the subject's baselines only)
+struct Subject {
+    double Bglc, S0glg, KINglc, KINins, KINglp, KINglg, KINgip;
+};
+
+__device__ inline Subject subject_init(const FourGIPar &p, const double *bsl)
+{
+    Subject s;
+    const double Bglc = bsl[0], Bins = bsl[1], Bglp = bsl[2], Bglg = bsl[3], Bgip = bsl[4];
+    const double r0 = pow(Bglp / p.EC50_1, p.HILL_1);
+    const double S0ins = p.EMAX_1 * r0 / (1.0 + r0);
+    const double q0 = Bglg / p.EC50_4;
+    s.Bglc = Bglc;
+    s.S0glg = p.EMAX_4 * q0 / (1.0 + q0);
+    s.KINglc = Bglc * (p.CLglc + p.CLglci * Bins);
+    s.KINins = Bins * p.CLins / (1.0 + S0ins * pow(Bglc, p.GLCINS_S));
+    s.KINglp = p.VM_GLP * Bglp * p.VCglp / (p.KM_GLP + Bglp);
+    s.KINglg = Bglg * p.CLglg;
+    s.KINgip = Bgip * p.CLgip;
+    return s;
+}
+
+// generate4GI.py:73-157.  y = amounts (Gc, Ins, GLP, Glg, GIP, Gp, InsE, GIPp); meal = glucose input rate of the interval
+__device__ __forceinline__ void fourgi_rhs(const FourGIPar &p, const Subject &s, int hv, const double *y, double meal,
+                                           double *d)
+{
+    const double Cglc = y[0] / p.VCglc, Cins = y[1] / p.VCins, Cglp = y[2] / p.VCglp, Cglg = y[3] / p.VCglg;
+    const double r = pow(Cglp / p.EC50_1, p.HILL_1);
+    const double Sins = p.EMAX_1 * r / (1.0 + r);
+    const double q = Cglg / p.EC50_4;
+    const double Sglg = p.EMAX_4 * q / (1.0 + q);
+    const double glg_on_glc = (1.0 + Sglg) / (1.0 + s.S0glg);
+    const double p2 = Cglc >= s.Bglc ? 0.925 : (hv ? 0.327 : 0.0);
+    const double glc_on_glg = Cglc > 0.0 ? pow(s.Bglc / Cglc, p2) : 1.0;
+    const double me = meal * 10.0;
+    const bool fed = me > 0.0;
+    const double fglp = fed ? p.FDGLP * me : 0.0, fgip = fed ? p.FDGIP * me : 0.0, fglg = fed ? p.FDGLG * me : 0.0;
+    const double k27 = p.Qglc / p.VCglc, k72 = p.Qglc / p.VPglc, k612 = p.Qgip / p.VCgip, k126 = p.Qgip / p.VPgip;
+    d[0] = meal + s.KINglc * glg_on_glc - k27 * y[0] + k72 * y[5] - (p.CLglc / p.VCglc) * y[0] -
+           (p.CLglci * y[6] / p.VCglc) * y[0];
+    d[1] = s.KINins * (1.0 + Sins * pow(Cglc, p.GLCINS_S)) - (p.CLins / p.VCins) * y[1];
+    d[2] = s.KINglp * (1.0 + fglp) - p.VM_GLP * Cglp / (p.KM_GLP + Cglp);
+    d[3] = s.KINglg * (1.0 + fglg) * glc_on_glg - (p.CLglg / p.VCglg) * y[3];
+    d[4] = s.KINgip * (1.0 + fgip) - (p.CLgip / p.VCgip) * y[4] - k612 * y[4] + k126 * y[7];
+    d[5] = k27 * y[0] - k72 * y[5];
+    d[6] = p.Ke0ins * (Cins - y[6]);
+    d[7] = k612 * y[4] - k126 * y[7];
+}
+
+__global__ __launch_bounds__(64) void fourgi_rhs_kernel(int B, int hv, FourGIPar p, const double *__restrict__ bsl,
+                                                        const double *__restrict__ y, const double *__restrict__ meal,
+                                                        double *__restrict__ d)
+{
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= B) return;
+    const Subject s = subject_init(p, bsl + 5 * (size_t)b);
+    double yy[8], dd[8];
+    for (int i = 0; i < 8; ++i) yy[i] = y[8 * (size_t)b + i];
+    fourgi_rhs(p, s, hv, yy, meal[b], dd);
+    for (int i = 0; i < 8; ++i) d[8 * (size_t)b + i] = dd[i];
+}
+
+__device__ inline double grid_hours(int k, double interval_min) { return ((double)k * interval_min) / 60.0; }
+
+// numpy: data + normal(0, cv * |data|) = data + ((cv) * |data|) * z -- every operation rounded, no fma contraction
+__device__ inline double add_noise(double v, double cv, double z)
+{
+#pragma clang fp contract(off)
+    const double scale = cv * fabs(v);
+    const double noise = scale * z;
+    return v + noise;
+}
+
+// one row of the table (generate4GI.py:198-205 amounts -> concentrations, :214-219 noise, :246-257 columns)
+__device__ inline void emit_row(const GenArgs &a, int b, int k, const double *y, bool ok, const double *mt, int n_meals)
+{
+    const FourGIPar &p = a.par;
+    double *row = a.table + ((size_t)b * a.T + k) * 9;
+    const double th = grid_hours(k, a.interval_min);
+    row[0] = (double)(a.subject0 + b);
+    row[1] = th;
+    row[2] = th * 60.0;
+    const double conc[5] = {y[0] / p.VCglc, y[1] / p.VCins, y[2] / p.VCglp, y[3] / p.VCglg, y[4] / p.VCgip};
+    const double cvs[5] = {1.0, 1.5, 1.5, 1.2, 1.3};
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+        double v = ok ? conc[c] : 0.0;
+        if (a.z != nullptr && a.noise_cv != 0.0) {
+            const double zz = a.z[((size_t)b * 5 + c) * a.T + k];
+            v = add_noise(v, a.noise_cv * cvs[c], zz);   // generate4GI.py:239-243: cv = noise_cv * {1, 1.5, 1.5, 1.2, 1.3}
+        }
+        row[3 + c] = v;
+    }
+    bool ind = false;
+    for (int m = 0; m < n_meals; ++m) ind = ind || (fabs(th - mt[m]) < 0.01);
+    row[8] = ind ? 1.0 : 0.0;
+}
+
+__global__ __launch_bounds__(64) void fourgi_generate_kernel(GenArgs a)
+{
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= a.B) return;
+    const FourGIPar &p = a.par;
+    const Subject s = subject_init(p, a.bsl + 5 * (size_t)b);
+    const double *mt = a.meal_time + (a.meals_per_subject ? (size_t)b * a.n_meals : 0);
+    const double *ms = a.meal_size + (a.meals_per_subject ? (size_t)b * a.n_meals : 0);
+    const double Bins = a.bsl[5 * (size_t)b + 1], Bglp = a.bsl[5 * (size_t)b + 2], Bglg = a.bsl[5 * (size_t)b + 3],
+                 Bgip = a.bsl[5 * (size_t)b + 4];
+    // generate4GI.py:175-184
+    double y[8] = {s.Bglc * p.VCglc, Bins * p.VCins, Bglp * p.VCglp, Bglg * p.VCglg,
+                   Bgip * p.VCgip,   s.Bglc * p.VPglc, Bins,         Bgip * p.VPgip};
+    double K[7][8], w[8], d[8];
+#pragma unroll
+    for (int j = 0; j < 7; ++j)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) K[j][i] = 0.0;
+
+    auto meal_rate = [&](int k, double &H) {  // generate4GI.py:191-197: the meal is spread over its grid interval
+        const double t0 = grid_hours(k, a.interval_min), t1 = grid_hours(k + 1, a.interval_min);
+        H = t1 - t0;
+        double rate = 0.0;
+        for (int m = 0; m < a.n_meals; ++m)
+            if (t0 <= mt[m] && mt[m] < t1) rate = ms[m] / H;
+        return rate;
+    };
+
+    int k = 0, status = 0, it = 0;
+    emit_row(a, b, 0, y, true, mt, a.n_meals);
+    if (a.T > 1) {
+        double H, tau = 0.0;
+        double rate = meal_rate(0, H);
+        double h = H;
+        bool need0 = true;
+        while (true) {
+            bool last = false;
+            if (tau + h >= H * (1.0 - 1e-14)) {
+                h = H - tau;
+                last = true;
+            }
+            if (h < 1e-14 * H) {
+                status = HODE_ST_UNDERFLOW;
+                break;
+            }
+#pragma unroll 1
+            for (int st = need0 ? 0 : 1; st <= 6; ++st) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    double acc = kDP[st][0] * K[0][i];
+#pragma unroll
+                    for (int j = 1; j < 6; ++j) acc += kDP[st][j] * K[j][i];
+                    w[i] = y[i] + h * acc;
+                }
+                fourgi_rhs(p, s, a.hv, w, rate, d);
+                switch (st) {  // static register indices: K never goes to scratch
+#define HODE_PUT(J) \
+    case J: \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i) K[J][i] = d[i]; \
+        break;
+                    HODE_PUT(0) HODE_PUT(1) HODE_PUT(2) HODE_PUT(3) HODE_PUT(4) HODE_PUT(5)
+                default:
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) K[6][i] = d[i];
+#undef HODE_PUT
+                }
+            }
+            need0 = false;
+            // after stage 6: w = y_new, K[6] = f(y_new)
+            double acc = 0.0;
+            bool finite = true;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                double e = kDPE[0] * K[0][i];
+#pragma unroll
+                for (int j = 2; j < 7; ++j) e += kDPE[j] * K[j][i];
+                e *= h;
+                const double sc = a.atol + a.rtol * fmax(fabs(y[i]), fabs(w[i]));
+                acc += (e / sc) * (e / sc);
+                finite = finite && isfinite(w[i]);
+            }
+            if (!finite) {
+                status = HODE_ST_NONFINITE;
+                break;
+            }
+            const double err = sqrt(acc / 8.0);
+            if (err < 1.0) {
+                const double fac = err == 0.0 ? 10.0 : fmin(10.0, 0.9 * pow(err, -0.2));
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    y[i] = w[i];
+                    K[0][i] = K[6][i];
+                }
+                if (last) {
+                    ++k;
+                    emit_row(a, b, k, y, true, mt, a.n_meals);
+                    if (k == a.T - 1) break;
+                    const double nr = meal_rate(k, H);
+                    need0 = nr != rate;  // same input => the FSAL stage IS the first stage of the next interval
+                    rate = nr;
+                    tau = 0.0;
+                    h *= fac;
+                    if (!(h > 0.0) || h > H) h = H;
+                    it = 0;
+                    continue;
+                }
+                tau += h;
+                h *= fac;
+            } else {
+                h *= fmax(0.2, 0.9 * pow(err, -0.2));
+            }
+            if (++it >= a.max_steps) {
+                status = HODE_ST_MAXSTEPS;
+                break;
+            }
+        }
+    }
+    for (int kk = k + 1; kk < a.T; ++kk) emit_row(a, b, kk, y, false, mt, a.n_meals);  // rows after a failure: zeros
+    if (a.status) a.status[b] = status;
+}
+
+int launch_4gi_generate(hipStream_t s, const GenArgs &a)
+{
+    if (a.B <= 0) return HODE_OK;
+    hipLaunchKernelGGL(fourgi_generate_kernel, dim3((a.B + 63) / 64), dim3(64), 0, s, a);
+    return hipGetLastError() == hipSuccess ? HODE_OK : HODE_ELAUNCH;
+}
+
+int launch_4gi_rhs(hipStream_t s, int B, int hv, const FourGIPar &p, const double *bsl, const double *y, const double *meal,
+                   double *d)
+{
+    if (B <= 0) return HODE_OK;
+    hipLaunchKernelGGL(fourgi_rhs_kernel, dim3((B + 63) / 64), dim3(64), 0, s, B, hv, p, bsl, y, meal, d);
+    return hipGetLastError() == hipSuccess ? HODE_OK : HODE_ELAUNCH;
+}
+
+// --------------------------------------------------------------------------------------------- K8: windows
+constexpr int kWinBlocks = 256;   // fixed number of partial sums => deterministic reduction
+constexpr int kWinThreads = 256;
+
+__device__ inline double win_value(const WinArgs &a, int64_t row, int c)
+{
+    const int col = a.col_state[c];
+    // train_hybrid.py:76-80: absent 'ge' -> 0.0, absent 'ffa' -> 1.0
+    return col >= 0 ? a.table[row * a.ncols + col] : (c == 5 ? 1.0 : 0.0);
+}
+
+// pass = 0: partial[block][c] = sum x ; pass = 1: partial[block][c] = sum (x - mean_c)^2   (numpy.std is two-pass)
+__global__ __launch_bounds__(kWinThreads) void win_moment_kernel(WinArgs a, int pass, const double *__restrict__ mean,
+                                                                 double *__restrict__ partial)
+{
+    __shared__ double red[kWinThreads / 64][6];
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    double mu[6] = {0, 0, 0, 0, 0, 0};
+    if (pass)
+        for (int c = 0; c < 6; ++c) mu[c] = mean[c];
+    const int64_t total = a.N * a.S;
+    // contiguous chunk per block, fixed by (N, S) alone
+    const int64_t per = (total + kWinBlocks - 1) / kWinBlocks;
+    const int64_t lo = per * blockIdx.x, hi = lo + per < total ? lo + per : total;
+    for (int64_t e = lo + threadIdx.x; e < hi; e += kWinThreads) {
+        const int64_t row = a.row0[e / a.S] + e % a.S;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            const double x = win_value(a, row, c) - mu[c];
+            acc[c] += pass ? x * x : x;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+        double v = acc[c];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);   // butterfly: the same order in every run
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][c] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        double v = 0.0;
+        for (int wv = 0; wv < kWinThreads / 64; ++wv) v += red[wv][threadIdx.x];
+        partial[blockIdx.x * 6 + threadIdx.x] = v;
+    }
+}
+
+// pass 0: mean_std[c] = sum/count ; pass 1: mean_std[6+c] = sqrt(sum/count) + 1e-6   (train_hybrid.py:124-127)
+__global__ void win_finish_kernel(int pass, int64_t count, const double *__restrict__ partial, double *__restrict__ mean_std)
+{
+    const int c = threadIdx.x;
+    if (c >= 6) return;
+    double v = 0.0;
+    for (int blk = 0; blk < kWinBlocks; ++blk) v += partial[blk * 6 + c];
+    v /= (double)count;
+    if (pass == 0)
+        mean_std[c] = v;
+    else
+        mean_std[6 + c] = sqrt(v) + 1e-6;
+}
+
+__global__ void win_identity_kernel(double *mean_std)
+{
+    if (threadIdx.x < 6) {
+        mean_std[threadIdx.x] = 0.0;
+        mean_std[6 + threadIdx.x] = 1.0;
+    }
+}
+
+// one thread per (window, position): train_hybrid.py:113-121 (slices) and :133-154 (normalise, cast to fp32)
+__global__ __launch_bounds__(256) void win_emit_kernel(WinArgs a, const double *__restrict__ mean_std)
+{
+    const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (e >= a.N * a.S) return;
+    const int64_t row = a.row0[e / a.S] + e % a.S;
+    float st[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) st[c] = (float)((win_value(a, row, c) - mean_std[c]) / mean_std[6 + c]);
+    float2 *o = reinterpret_cast<float2 *>(a.states + e * 6);   // 24-byte records, 8-byte aligned
+    o[0] = make_float2(st[0], st[1]);
+    o[1] = make_float2(st[2], st[3]);
+    o[2] = make_float2(st[4], st[5]);
+    a.meal[e] = a.col_meal >= 0 ? (float)a.table[row * a.ncols + a.col_meal] : 0.f;
+    a.tvns[e] = a.col_tvns >= 0 ? (float)a.table[row * a.ncols + a.col_tvns] : 0.f;
+    a.time[e] = (float)(a.table[row * a.ncols + a.col_time] / a.time_div);
+}
+
+int launch_4gi_windows(hipStream_t s, const WinArgs &a, int normalize, double *mean_std, void *scratch)
+{
+    const int64_t total = a.N * a.S;
+    if (total <= 0) {
+        hipLaunchKernelGGL(win_identity_kernel, dim3(1), dim3(64), 0, s, mean_std);
+        return hipGetLastError() == hipSuccess ? HODE_OK : HODE_ELAUNCH;
+    }
+    double *partial = (double *)scratch;
+    if (normalize) {
+        for (int pass = 0; pass < 2; ++pass) {
+            hipLaunchKernelGGL(win_moment_kernel, dim3(kWinBlocks), dim3(kWinThreads), 0, s, a, pass, mean_std, partial);
+            hipLaunchKernelGGL(win_finish_kernel, dim3(1), dim3(64), 0, s, pass, total, partial, mean_std);
+        }
+    } else {
+        hipLaunchKernelGGL(win_identity_kernel, dim3(1), dim3(64), 0, s, mean_std);
+    }
+    const int64_t blocks = (total + 255) / 256;
+    if (blocks > 0x7fffffff) return HODE_EUNSUPPORTED;
+    hipLaunchKernelGGL(win_emit_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a, mean_std);
+    return hipGetLastError() == hipSuccess ? HODE_OK : HODE_ELAUNCH;
+}
+
+}  // namespace hode

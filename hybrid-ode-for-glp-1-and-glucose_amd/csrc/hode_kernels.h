@@ -46,6 +46,39 @@ int launch_adam(hipStream_t s, int64_t n, float *p, const float *g, float *m, fl
 int launch_mse(hipStream_t s, int64_t n, const float *y, const float *obs, float scale, double *loss, float *gy);
 int launch_selftest(hipStream_t s, int32_t *out);
 
+// ---- data side (hode_datagen.hip) ----------------------------------------------------------------------------
+// 4GI model parameters, in the order of include/hode.h (HODE_4GI_NPAR)
+struct FourGIPar {
+    double CLglc, CLglci, Qglc, VCglc, VPglc, CLins, VCins, Ke0ins, VCglp, VM_GLP, KM_GLP, CLglg, VCglg, CLgip, VCgip,
+        Qgip, VPgip, GLCINS_S, EMAX_1, EC50_1, HILL_1, EMAX_4, EC50_4, FDGLP, FDGIP, FDGLG;
+};
+static_assert(sizeof(FourGIPar) == HODE_4GI_NPAR * sizeof(double), "parameter block layout");
+
+struct GenArgs {
+    int B, T, hv, n_meals, meals_per_subject, max_steps;
+    int64_t subject0;
+    double interval_min, rtol, atol, noise_cv;
+    const double *bsl, *meal_time, *meal_size, *z;
+    double *table;      // [B*T][9]
+    int32_t *status;
+    FourGIPar par;
+};
+
+struct WinArgs {
+    const double *table;
+    int ncols, col_time, col_meal, col_tvns;
+    int col_state[6];   // glucose, insulin, glucagon, glp1, ge, ffa  (-1 = absent)
+    double time_div;
+    const int64_t *row0;  // [N] first table row of every window
+    int64_t N, S;
+    float *states, *meal, *tvns, *time;
+};
+
+int launch_4gi_generate(hipStream_t s, const GenArgs &a);
+int launch_4gi_rhs(hipStream_t s, int B, int hv, const FourGIPar &p, const double *bsl, const double *y, const double *meal,
+                   double *d);
+int launch_4gi_windows(hipStream_t s, const WinArgs &a, int normalize, double *mean_std, void *scratch);
+
 // tape = entries | interval indices | (256-byte aligned) stage tape
 inline size_t tape_seg_offset(int B, int max_steps, size_t elem) { return (size_t)B * max_steps * 8 * elem; }
 inline size_t tape_stage_offset(int B, int max_steps, size_t elem)

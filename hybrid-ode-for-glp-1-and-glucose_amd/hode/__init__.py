@@ -8,3 +8,4 @@ from . import _capi as capi  # noqa: F401
 from ._capi import (METHOD_DP54, METHOD_RK4, HodeError, adam_step, lib_path, load, mse_fwd_bwd, n_params,  # noqa: F401
                     rhs_bwd, rhs_fwd, selftest_xlane, solve_bwd, solve_fwd, version)
 from . import train  # noqa: F401,E402
+from . import datagen  # noqa: F401,E402

@@ -20,7 +20,8 @@ _ERR = {-1: "HODE_EINVAL (bad argument)", -2: "HODE_EUNSUPPORTED (shape outside 
 SYMBOLS = ["hode_version", "hode_nn_param_count", "hode_tape_bytes", "hode_rhs_fwd_f32", "hode_rhs_fwd_f64",
            "hode_rhs_bwd_f32", "hode_rhs_bwd_f64", "hode_solve_fwd_f32", "hode_solve_fwd_f64",
            "hode_solve_bwd_f32", "hode_solve_bwd_f64", "hode_adam_step_f32", "hode_mse_fwd_bwd_f32",
-           "hode_selftest_xlane"]
+           "hode_selftest_xlane", "hode_4gi_default_params", "hode_4gi_generate_f64", "hode_4gi_rhs_f64",
+           "hode_4gi_windows_f32"]
 
 
 class HodeError(RuntimeError):
@@ -249,3 +250,98 @@ def mse_fwd_bwd(y, obs, scale, loss_sum=None, want_grad=True):
     _check(load().hode_mse_fwd_bwd_f32(_stream(), C.c_int64(y.numel()), _ptr(y), _ptr(obs), C.c_float(scale),
                                        _ptr(loss_sum), _ptr(gy)), "hode_mse_fwd_bwd")
     return loss_sum, gy
+
+
+# --------------------------------------------------------------------------------------------- data side
+FOURGI_NPAR = 26
+FOURGI_SCRATCH_BYTES = 16384
+FOURGI_COLUMNS = ["subject_id", "time_hours", "time_minutes", "glucose_mmol_L", "insulin_pmol_L", "glp1_pmol_L",
+                  "glucagon_pmol_L", "gip_pmol_L", "meal_indicator"]
+
+
+def fourgi_default_params(patient_type="T2DM"):
+    """The reference's parameter set (data/generate4GI.py:15-64) as a list of 26 floats (host call, no GPU needed)."""
+    buf = (C.c_double * FOURGI_NPAR)()
+    _check(load().hode_4gi_default_params(C.c_int(_ptype(patient_type)), buf), "hode_4gi_default_params")
+    return list(buf)
+
+
+def _ptype(patient_type):
+    if patient_type in ("T2DM", 0):
+        return 0
+    if patient_type in ("HV", 1):
+        return 1
+    raise HodeError(f"patient_type must be 'T2DM' or 'HV', got {patient_type!r}")
+
+
+def _par_host(par):
+    if par is None:
+        return None
+    if len(par) != FOURGI_NPAR:
+        raise HodeError(f"par must hold {FOURGI_NPAR} values")
+    return (C.c_double * FOURGI_NPAR)(*[float(v) for v in par])
+
+
+def fourgi_generate(bsl, T, interval_min, meal_time, meal_size, patient_type="T2DM", par=None, z=None, noise_cv=0.0,
+                    subject0=0, rtol=1e-10, atol=1e-12, max_steps=100000):
+    """K7.  bsl[B,5] (device, fp64) -> (table[B*T,9] fp64, status[B] int32).  meal_time/meal_size: [n] or [B,n]."""
+    _need_gpu(bsl)
+    dev = bsl.device
+    bsl = bsl.to(torch.float64).contiguous().view(-1, 5)
+    B = bsl.shape[0]
+    mt = torch.as_tensor(meal_time, dtype=torch.float64, device=dev).contiguous()
+    ms = torch.as_tensor(meal_size, dtype=torch.float64, device=dev).contiguous()
+    if mt.shape != ms.shape or mt.dim() not in (1, 2) or (mt.dim() == 2 and mt.shape[0] != B):
+        raise HodeError(f"meal_time / meal_size must both be [n_meals] or [B,n_meals], got {tuple(mt.shape)} / {tuple(ms.shape)}")
+    n_meals = mt.shape[-1]
+    if z is not None:
+        z = z.to(device=dev, dtype=torch.float64).contiguous()
+        if tuple(z.shape) != (B, 5, T):
+            raise HodeError(f"z must be [B,5,T]=({B},5,{T}), got {tuple(z.shape)}")
+    table = torch.empty(B * T, 9, dtype=torch.float64, device=dev)
+    status = torch.empty(B, dtype=torch.int32, device=dev)
+    _check(load().hode_4gi_generate_f64(
+        _stream(), C.c_int(B), C.c_int(T), C.c_double(interval_min), C.c_int(_ptype(patient_type)), _par_host(par),
+        _ptr(bsl), C.c_int(n_meals), _ptr(mt if n_meals else None), _ptr(ms if n_meals else None), C.c_int(int(mt.dim() == 2)),
+        _ptr(z), C.c_double(noise_cv), C.c_int64(subject0), C.c_double(rtol), C.c_double(atol), C.c_int(max_steps),
+        _ptr(table), _ptr(status)), "hode_4gi_generate_f64")
+    return table, status
+
+
+def fourgi_rhs(bsl, y, meal, patient_type="T2DM", par=None):
+    _need_gpu(y)
+    dev = y.device
+    y = y.to(torch.float64).contiguous().view(-1, 8)
+    B = y.shape[0]
+    bsl = bsl.to(device=dev, dtype=torch.float64).contiguous().view(-1, 5)
+    meal = meal.to(device=dev, dtype=torch.float64).contiguous().view(-1)
+    assert bsl.shape[0] == B and meal.shape[0] == B
+    d = torch.empty_like(y)
+    _check(load().hode_4gi_rhs_f64(_stream(), C.c_int(B), C.c_int(_ptype(patient_type)), _par_host(par), _ptr(bsl), _ptr(y),
+                                   _ptr(meal), _ptr(d)), "hode_4gi_rhs_f64")
+    return d
+
+
+def fourgi_windows(table, cols, time_div, row0, seq_len, normalize=True):
+    """K8.  table[rows,ncols] fp64 (device); cols: dict time/glucose/insulin/glucagon/glp1 (+ optional ge/ffa/meal/tvns)
+    -> column index; row0[N] int64 (device).  -> states[N,S,6], meal[N,S], tvns[N,S], time[N,S] (fp32), mean_std[12] (fp64)."""
+    _need_gpu(table)
+    dev = table.device
+    if table.dtype != torch.float64 or table.dim() != 2:
+        raise HodeError("table must be a 2-D float64 tensor")
+    table = table.contiguous()
+    row0 = row0.to(device=dev, dtype=torch.int64).contiguous()
+    N, S = row0.numel(), int(seq_len)
+    if N and (int(row0.min()) < 0 or int(row0.max()) + S > table.shape[0]):
+        raise HodeError("window outside the table")     # checked on the host BEFORE the launch
+    states = torch.empty(N, S, 6, dtype=torch.float32, device=dev)
+    meal, tvns, time = (torch.empty(N, S, dtype=torch.float32, device=dev) for _ in range(3))
+    mean_std = torch.empty(12, dtype=torch.float64, device=dev)
+    scratch = torch.empty(FOURGI_SCRATCH_BYTES, dtype=torch.uint8, device=dev)
+    g = lambda k: C.c_int(int(cols.get(k, -1)))
+    _check(load().hode_4gi_windows_f32(
+        _stream(), _ptr(table), C.c_int(table.shape[1]), g("time"), C.c_double(time_div), g("glucose"), g("insulin"),
+        g("glucagon"), g("glp1"), g("ge"), g("ffa"), g("meal"), g("tvns"), _ptr(row0), C.c_int64(N), C.c_int64(S),
+        C.c_int(int(bool(normalize))), _ptr(states), _ptr(meal), _ptr(tvns), _ptr(time), _ptr(mean_std), _ptr(scratch)),
+        "hode_4gi_windows_f32")
+    return states, meal, tvns, time, mean_std

@@ -138,6 +138,51 @@ int hode_mse_fwd_bwd_f32(void *stream, int64_t n, const float *y, const float *o
 /* ---- self test of the cross-lane primitives (DPP / permlane swaps); out: int32[64*8].        */
 int hode_selftest_xlane(void *stream, int32_t *out);
 
+/* =====================================================================================================
+ * Data side: the cohort generator and the dataset windows, on the device.
+ * ===================================================================================================== */
+#define HODE_4GI_NPAR 26       /* CLglc CLglci Qglc VCglc VPglc CLins VCins Ke0ins VCglp VM_GLP KM_GLP CLglg VCglg
+                                  CLgip VCgip Qgip VPgip GLCINS_S EMAX_1 EC50_1 HILL_1 EMAX_4 EC50_4 FDGLP FDGIP FDGLG */
+#define HODE_4GI_T2DM 0
+#define HODE_4GI_HV 1
+#define HODE_4GI_TABLE_COLS 9  /* subject_id time_hours time_minutes glucose_mmol_L insulin_pmol_L glp1_pmol_L
+                                  glucagon_pmol_L gip_pmol_L meal_indicator  (data/generate4GI.py:246-257) */
+#define HODE_4GI_SCRATCH_BYTES 16384
+
+/* the reference's parameter set (data/generate4GI.py:15-64) for a patient type -> par[HODE_4GI_NPAR] (HOST memory) */
+int hode_4gi_default_params(int patient_type, double *par_host);
+
+/* ---- K7: 4GI cohort generator.  Replaces FourGIModel.simulate (data/generate4GI.py:159-212: one scipy odeint call
+ *      per subject per grid interval) and the table assembly of generate_dataset (:221-271) for B subjects at once.
+ *      One subject per wavefront lane, fp64, DP5(4) at (rtol, atol) inside every grid interval.
+ *      T grid points at k*interval_min minutes; bsl[B,5] = the subject's baselines (glucose, insulin, GLP-1, glucagon,
+ *      GIP); meals: meal_time/meal_size [n_meals] shared by all subjects (meals_per_subject = 0) or [B,n_meals];
+ *      par_host: HOST pointer to HODE_4GI_NPAR doubles or NULL (= hode_4gi_default_params(patient_type));
+ *      z[B,5,T]: standard-normal draws for the measurement noise (order glucose, insulin, glp1, glucagon, gip = the
+ *      order generate_dataset consumes numpy's global stream) or NULL / noise_cv = 0 for the clean solution;
+ *      table[B*T, 9] written, subject ids start at subject0; status[B] (may be NULL) as in hode_solve_fwd.          */
+int hode_4gi_generate_f64(void *stream, int B, int T, double interval_min, int patient_type, const double *par_host,
+                          const double *bsl, int n_meals, const double *meal_time, const double *meal_size,
+                          int meals_per_subject, const double *z, double noise_cv, int64_t subject0, double rtol,
+                          double atol, int max_steps, double *table, int32_t *status);
+
+/* 4GI right-hand side alone (FourGIModel.model_equations, data/generate4GI.py:73-157): y[B,8], meal[B] -> d[B,8] */
+int hode_4gi_rhs_f64(void *stream, int B, int patient_type, const double *par_host, const double *bsl, const double *y,
+                     const double *meal, double *d);
+
+/* ---- K8: sliding windows + z-scoring.  Replaces GlucoseDataset.__init__/__getitem__ (train/train_hybrid.py:43-155).
+ *      table[rows, ncols] fp64 row-major; col_* = column indices (col_ge / col_ffa / col_meal / col_tvns may be -1:
+ *      0, 1, 0, 0 as in :76-91); time = table[:, col_time] / time_div (60 for time_minutes, :93-94);
+ *      row0[N] (device int64) = first table row of every window (subject by subject, start += stride, :105-121);
+ *      normalize != 0: mean/std over ALL window rows (overlaps counted as often as they occur, numpy two-pass std,
+ *      + 1e-6; :124-127), else mean 0 / std 1.  Written: states[N,S,6] fp32 (observations; initial_state = [:,0]),
+ *      meal[N,S], tvns[N,S], time[N,S] fp32, mean_std[12] fp64 (6 means, 6 stds).
+ *      scratch: HODE_4GI_SCRATCH_BYTES of device memory.  Deterministic (no atomics).                              */
+int hode_4gi_windows_f32(void *stream, const double *table, int ncols, int col_time, double time_div, int col_glucose,
+                         int col_insulin, int col_glucagon, int col_glp1, int col_ge, int col_ffa, int col_meal,
+                         int col_tvns, const int64_t *row0, int64_t N, int64_t S, int normalize, float *states,
+                         float *meal, float *tvns, float *time, double *mean_std, void *scratch);
+
 #ifdef __cplusplus
 }
 #endif

@@ -21,7 +21,7 @@ METHOD_RK4 = 1
 
 def build(force=False):
     """Compile the C restatement with gcc (seconds)."""
-    src = [os.path.join(_HERE, f) for f in ("hode_oracle.c", "hode_oracle_impl.h")]
+    src = [os.path.join(_HERE, f) for f in ("hode_oracle.c", "hode_oracle_impl.h", "fourgi_oracle.c")]
     if (not force) and os.path.exists(_SO) and all(os.path.getmtime(_SO) >= os.path.getmtime(s) for s in src):
         return _SO
     subprocess.run(["make", "-C", _HERE, "-s"], check=True)

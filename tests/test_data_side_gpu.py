@@ -1,0 +1,217 @@
+"""Data side, GPU part: kernels K7 (4GI cohort generator) and K8 (dataset windows) through the C ABI
+against the oracle and against vectors captured from the reference (data/generate4GI.py, train/train_hybrid.py:43-155)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from _data_helpers import frame_from_table, reference_stream
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _g(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def _t(a):
+    return torch.as_tensor(np.ascontiguousarray(a), device=DEV)
+
+
+def _conc(table, B, T):
+    return table.view(B, T, 9)[:, :, 3:8].cpu().numpy()
+
+
+@pytest.mark.parametrize("ptype", ["T2DM", "HV"])
+def test_k7_rhs_vs_reference(golden_dir, ptype):
+    import hode
+    g = _g(golden_dir, f"g8_rhs_{ptype}.npz")
+    d = hode.capi.fourgi_rhs(_t(g["bsl"]), _t(g["y"]), _t(g["meal"]), ptype).cpu().numpy()
+    # fp64, same formulae; device pow / fma contraction differ from numpy in the last bits, and d is a difference of
+    # production and elimination terms: tolerance relative to the row scale
+    scale = np.abs(g["d"]).max(1, keepdims=True)
+    assert (np.abs(d - g["d"]) / scale).max() < 1e-13
+
+
+@pytest.mark.parametrize("case", range(5))
+def test_k7_clean_trajectories_vs_oracle_and_reference(golden_dir, case):
+    import hode
+    from oracle import fourgi
+    g = _g(golden_dir, f"g8_sim_{case}.npz")
+    T, dt, ptype = len(g["t_hours"]), float(g["interval_min"]), str(g["patient_type"])
+    B = g["bsl"].shape[0]
+    table, status = hode.capi.fourgi_generate(_t(g["bsl"]), T, dt, g["meal_time"], g["meal_size"], ptype)
+    assert (status == 0).all()
+    conc = _conc(table, B, T)
+    want, _, _ = fourgi.simulate(g["bsl"], T, dt, g["meal_time"], g["meal_size"], ptype)
+    np.testing.assert_allclose(conc, want, rtol=1e-7, atol=0)            # same algorithm and tolerances; pow / fma differ in
+    # the last bits, so an accept/reject decision can flip: agreement at the level of the converged error, not bitwise
+    np.testing.assert_allclose(conc, g["conc"], rtol=2e-6, atol=0)       # the reference (LSODA at 1.49e-8)
+    tab = table.cpu().numpy().reshape(B, T, 9)
+    assert np.array_equal(tab[0, :, 1], g["t_hours"]) and np.array_equal(tab[:, :, 2], tab[:, :, 1] * 60)
+    assert np.array_equal(tab[:, 0, 0], np.arange(B))
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_k7_seeded_dataset_reproduces_the_reference_table(golden_dir, seed):
+    """FourGIModel.generate_dataset under np.random.seed(seed) == the reference's generate_dataset under the same seed."""
+    from hode.datagen import FourGIModel
+    g = _g(golden_dir, f"g8_dataset_seed{seed}.npz")
+    np.random.seed(seed)
+    df = FourGIModel("T2DM").generate_dataset(duration_hours=float(g["duration_hours"]),
+                                              sampling_interval_min=float(g["sampling_interval_min"]),
+                                              meal_times=list(g["meal_times"]), meal_sizes=list(g["meal_sizes"]),
+                                              noise_cv=float(g["noise_cv"]), n_subjects=int(g["n_subjects"]))
+    assert list(df.columns) == list(g["columns"])
+    tab, ref = df.values.astype(np.float64), g["table"]
+    assert tab.shape == ref.shape
+    for c in (0, 1, 2, 8):
+        assert np.array_equal(tab[:, c], ref[:, c])
+    np.testing.assert_allclose(tab[:, 3:8], ref[:, 3:8], rtol=2e-6, atol=0)
+
+
+def test_k7_noise_application_is_bitwise_numpy(golden_dir):
+    import hode
+    from oracle import fourgi
+    B, T = 37, 61
+    bsl, z = reference_stream(5, B, T)
+    clean, _ = hode.capi.fourgi_generate(_t(bsl), T, 5.0, [0.5, 2.5], [75, 50])
+    noisy, _ = hode.capi.fourgi_generate(_t(bsl), T, 5.0, [0.5, 2.5], [75, 50], z=_t(z), noise_cv=0.1, subject0=1000)
+    want = fourgi.dataset_table(_conc(clean, B, T), z, 5.0, [0.5, 2.5], 0.1, subject0=1000)
+    assert np.array_equal(noisy.cpu().numpy(), want)
+
+
+def test_k7_mirror_simulate_and_model_equations(golden_dir):
+    from hode.datagen import FourGIModel
+    g = _g(golden_dir, "g8_sim_1.npz")
+    m = FourGIModel("HV")
+    m.BSLglc, m.BSLins, m.BSLglp, m.BSLglg, m.BSLgip = g["bsl"][2]
+    t, *conc = m.simulate(5, 5, [1, 3], [75, 50])
+    assert np.array_equal(t, g["t_hours"])
+    np.testing.assert_allclose(np.stack(conc, 1), g["conc"][2], rtol=2e-6)
+    r = _g(golden_dir, "g8_rhs_HV.npz")
+    m.BSLglc, m.BSLins, m.BSLglp, m.BSLglg, m.BSLgip = r["bsl"][3]
+    d = np.array(m.model_equations(list(r["y"][3]), 0.0, float(r["meal"][3])))
+    assert np.abs(d - r["d"][3]).max() / np.abs(r["d"][3]).max() < 1e-13
+    # edited parameters are honoured (the reference object is plain attributes)
+    m.CLins *= 2
+    t2, _, ins2, *_ = m.simulate(5, 5, [1, 3], [75, 50])
+    assert ins2[-1] < 0.9 * conc[1][-1]
+
+
+def test_k7_per_subject_meals_and_status(golden_dir):
+    import hode
+    from oracle import fourgi
+    rng = np.random.default_rng(3)
+    B, T = 130, 49
+    bsl = fourgi.BASELINE * rng.normal(1, 0.1, size=(B, 5))
+    mt = rng.uniform(0.2, 3.8, size=(B, 3))
+    ms = rng.uniform(20, 90, size=(B, 3))
+    table, status = hode.capi.fourgi_generate(_t(bsl), T, 5.0, _t(mt), _t(ms), "HV")
+    want, st, _ = fourgi.simulate(bsl, T, 5.0, mt, ms, "HV")
+    assert (status.cpu().numpy() == st).all() and (st == 0).all()
+    np.testing.assert_allclose(_conc(table, B, T), want, rtol=1e-7)
+    # step budget exhausted: status 1, later rows zero (ids / times / meal column still filled)
+    table, status = hode.capi.fourgi_generate(_t(bsl[:5]), T, 5.0, _t(mt[:5]), _t(ms[:5]), "HV", max_steps=3)
+    want, st, _ = fourgi.simulate(bsl[:5], T, 5.0, mt[:5], ms[:5], "HV", max_steps=3)
+    assert (status.cpu().numpy() == 1).all() and (st == 1).all()
+    got = _conc(table, 5, T)
+    assert (got[:, 1:] == 0).all() and (want[:, 1:] == 0).all() and np.allclose(got[:, 0], want[:, 0])
+    assert (table.view(5, T, 9)[:, :, 1].cpu().numpy() == fourgi.grid_hours(T, 5.0)).all()
+    # empty cohort
+    table, status = hode.capi.fourgi_generate(torch.zeros(0, 5, dtype=torch.float64, device=DEV), T, 5.0, [1.0], [50.0])
+    assert table.shape == (0, 9)
+
+
+@pytest.mark.parametrize("name,src", [("4gi_61_30", None), ("4gi_20_10", None), ("4gi_20_7_raw", None),
+                                      ("ragged_20_10", "g9_frame_ragged.npz")])
+def test_k8_windows_vs_reference_dataset(golden_dir, name, src, tmp_path):
+    """GlucoseDataset mirror on a CSV written from the fixture table == the reference's GlucoseDataset on that data."""
+    import pandas as pd
+    from hode.datagen import GlucoseDataset
+    g = _g(golden_dir, f"g9_windows_{name}.npz")
+    t = _g(golden_dir, src or "g9_4gi_dataset_table.npz")
+    path = str(tmp_path / "frame.csv")
+    pd.DataFrame(t["table"], columns=list(t["columns"])).to_csv(path, index=False, float_format="%.17g")
+    ds = GlucoseDataset(path, sequence_length=int(g["seq_len"]), stride=int(g["stride"]), normalize=bool(g["normalize"]))
+    assert len(ds) == g["observations"].shape[0] and len(ds.state_cols) == 6
+    assert [int(s) for s in ds._subject_of_window] == g["subject_of_window"].tolist()
+    np.testing.assert_allclose(ds.state_mean, g["state_mean"], rtol=1e-12)
+    np.testing.assert_allclose(ds.state_std, g["state_std"], rtol=1e-12)
+    b = ds.batch(np.arange(len(ds)))
+    # z-scores are rounded to fp32 from fp64 values that agree to ~1e-13: at most one fp32 ulp apart
+    np.testing.assert_allclose(b["observations"].cpu().numpy(), g["observations"], rtol=2e-7, atol=1e-7)
+    assert np.array_equal(b["time_points"].cpu().numpy(), g["time_points"])
+    assert np.array_equal(b["external_inputs"]["meal"].cpu().numpy(), g["meal"])
+    assert np.array_equal(b["external_inputs"]["tVNS"].cpu().numpy(), g["tvns"])
+    item = ds[len(ds) - 1]
+    assert item["initial_state"].shape == (6,) and item["observations"].shape == (int(g["seq_len"]), 6)
+    np.testing.assert_allclose(item["initial_state"].numpy(), g["initial_state"][-1], rtol=2e-7, atol=1e-7)
+    raw = ds.sequences[0]
+    assert raw["states"].shape == (int(g["seq_len"]), 6) and (raw["states"][:, 5] == 1).all()
+
+
+def test_k8_vs_oracle_random_frames_and_edges():
+    import hode
+    from oracle import fourgi
+    rng = np.random.default_rng(11)
+    rows = 5000
+    tab = np.column_stack([rng.normal(50, 20, rows) for _ in range(7)] + [(rng.uniform(size=rows) < 0.05).astype(float)])
+    cols = dict(time=0, glucose=1, insulin=2, glucagon=3, glp1=4, ffa=5, tvns=6, meal=7)
+    off = np.array([0, 700, 710, 2500, 5000])
+    frame = dict(time=tab[:, 0] / 60.0, glucose=tab[:, 1], insulin=tab[:, 2], glucagon=tab[:, 3], glp1=tab[:, 4],
+                 ffa=tab[:, 5], tvns=tab[:, 6], meal=tab[:, 7])
+    for S, stride, norm in [(61, 30, True), (17, 1, True), (100, 250, False)]:
+        w = fourgi.windows(frame, off, S, stride, norm)
+        st, meal, tvns, time, ms = hode.capi.fourgi_windows(_t(tab), cols, 60.0, _t(w["row0"]), S, norm)
+        np.testing.assert_allclose(ms.cpu().numpy(), np.concatenate([w["mean"], w["std"]]), rtol=1e-12)
+        np.testing.assert_allclose(st.cpu().numpy(), w["states"], rtol=2e-7, atol=1e-7)
+        assert np.array_equal(meal.cpu().numpy(), w["meal"]) and np.array_equal(tvns.cpu().numpy(), w["tvns"])
+        assert np.array_equal(time.cpu().numpy(), w["time"])
+        # deterministic: the same call gives the same bits
+        st2, *_, ms2 = hode.capi.fourgi_windows(_t(tab), cols, 60.0, _t(w["row0"]), S, norm)
+        assert torch.equal(st, st2) and torch.equal(ms, ms2)
+    # no windows at all: identity statistics, empty batches
+    st, *_, ms = hode.capi.fourgi_windows(_t(tab), cols, 60.0, torch.zeros(0, dtype=torch.int64, device=DEV), 61, True)
+    assert st.shape == (0, 61, 6) and ms.cpu().tolist() == [0.0] * 6 + [1.0] * 6
+    with pytest.raises(hode.HodeError):
+        hode.capi.fourgi_windows(_t(tab), cols, 60.0, _t(np.array([rows - 10])), 61, True)
+
+
+def test_largest_cohort_generate_window_train():
+    """BASELINE config 4's 65 536 patients, generated, windowed and fed to the model without leaving the device."""
+    from hode.datagen import FourGIModel, GlucoseDataset
+    from models.hybrid_ode_nn import HybridODENN
+    B = 65536
+    gen = torch.Generator(device=DEV).manual_seed(0)
+    m = FourGIModel("T2DM")
+    table, status = m.generate_cohort(B, duration_hours=5, sampling_interval_min=5, meal_times=(0.5, 2.5), meal_sizes=(75, 50),
+                                      noise_cv=0.1, generator=gen)
+    T = 61
+    assert table.shape == (B * T, 9) and int((status != 0).sum()) == 0
+    v = table.view(B, T, 9)
+    assert torch.equal(v[:, 0, 0], torch.arange(B, device=DEV, dtype=torch.float64))
+    assert bool(torch.isfinite(table).all())
+    # subjects are independent: any shard of the cohort regenerates its rows bitwise (the multi-GPU split)
+    gen2 = torch.Generator(device=DEV).manual_seed(0)
+    bsl = torch.tensor([7.0, 50.0, 10.0, 25.0, 20.0], dtype=torch.float64, device=DEV) * (
+        1.0 + torch.tensor([0.1, 0.15, 0.15, 0.15, 0.15], dtype=torch.float64, device=DEV)
+        * torch.randn(B, 5, dtype=torch.float64, device=DEV, generator=gen2))
+    z = torch.randn(B, 5, T, dtype=torch.float64, device=DEV, generator=gen2)
+    import hode
+    lo, hi = 40000, 40000 + 8192
+    part, _ = hode.capi.fourgi_generate(bsl[lo:hi], T, 5.0, [0.5, 2.5], [75, 50], z=z[lo:hi], noise_cv=0.1, subject0=lo)
+    assert torch.equal(part, table[lo * T:hi * T])
+    ds = GlucoseDataset(table, sequence_length=31, stride=15)
+    assert len(ds) == B * 3
+    b = ds.batch(torch.arange(0, len(ds), 3))
+    obs = ds._states.double()
+    mean, std = obs.mean((0, 1)), obs.std((0, 1), unbiased=False)
+    assert float(mean[:4].abs().max()) < 1e-5 and float((std[:4] - 1).abs().max()) < 1e-4
+    assert float(obs[..., 4:].abs().max()) == 0.0
+    model = HybridODENN(device=DEV)
+    with torch.no_grad():
+        pred = model(b["initial_state"][:4096], b["time_points"][0], {k: u[:4096] for k, u in b["external_inputs"].items()})
+    assert pred.shape == (4096, 31, 6)
