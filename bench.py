@@ -94,6 +94,52 @@ def cpu_baseline(sample, seconds_budget=20.0):
             "per_core": sample / dt / ncores}
 
 
+def data_side(dev, B, cpu=True):
+    """SURVEY 8f-3 leg: generate a B-subject 4GI cohort (5 h at 5 min, 2 meals, 10 % noise: the reference's
+    data/generate4GI.py __main__ configuration) on the device, then cut and z-score the windows (31 / 15)."""
+    import hode
+    from hode.datagen import grid_points
+    T = grid_points(5, 5)
+    g = torch.Generator(device=dev).manual_seed(0)
+    base = torch.tensor([7.0, 50.0, 10.0, 25.0, 20.0], dtype=torch.float64, device=dev)
+    cv = torch.tensor([0.1, 0.15, 0.15, 0.15, 0.15], dtype=torch.float64, device=dev)
+    bsl = base * (1 + cv * torch.randn(B, 5, dtype=torch.float64, device=dev, generator=g))
+    z = torch.randn(T, 5, B, dtype=torch.float64, device=dev, generator=g)      # the kernel's layout
+
+    def timed(fn, reps=3):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            r = fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps, r
+    ms_gen, (table, status) = timed(lambda: hode.capi.fourgi_generate(bsl, T, 5.0, [0.5, 2.5], [75.0, 50.0], z_tcb=z, noise_cv=0.1))
+    S, stride = 31, 15
+    n_win = (T - S) // stride + 1
+    row0 = (torch.arange(B, device=dev)[:, None] * T + torch.arange(n_win, device=dev)[None, :] * stride).reshape(-1)
+    cols = dict(time=2, glucose=3, insulin=4, glucagon=6, glp1=5, meal=8)
+    ms_win, _ = timed(lambda: hode.capi.fourgi_windows(table, cols, 60.0, row0, S, True))
+    alg = table.numel() * 8 + row0.numel() * S * 9 * 4          # table read once + fp32 batches written once
+    out = {"workload": f"{B} subjects x {T} grid points (5 h at 5 min), T2DM, 2 meals, fp64 DP5(4) rtol 1e-10; windows {S}/{stride}",
+           "generate": {"ms": ms_gen, "subjects_per_s": B / ms_gen * 1e3, "failed": int((status != 0).sum()),
+                        "kernel": "fourgi_generate_kernel (one subject per lane)", "bound": "fp64 VALU latency (3 pow per RHS), 1 wave/SIMD"},
+           "windows": {"ms": ms_win, "windows": int(row0.numel()), "algorithmic_bytes": alg,
+                       "roofline": {"bound": "hbm", "achieved": alg / ms_win / 1e6, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                    "frac": alg / ms_win / 1e6 / PEAK_HBM_GBS}}}
+    if cpu:
+        from oracle import fourgi
+        n = 512
+        t0 = time.perf_counter()
+        fourgi.simulate(bsl[:n].cpu().numpy(), T, 5.0, [0.5, 2.5], [75.0, 50.0])
+        dt = time.perf_counter() - t0
+        out["generate"]["cpu_baseline"] = {"value": n / dt, "unit": "subjects/s", "cores": 1, "kind": "port",
+                                           "sample": f"{n} subjects of the same cohort, C oracle (DP5(4) at the same tolerances)"}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -104,6 +150,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=65536)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true")
+    ap.add_argument("--no-data-side", action="store_true")
+    ap.add_argument("--cohort", type=int, default=65536, help="subjects of the data-side leg (4GI generator + windows)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, default) | gloo (rehearsal: ranks may share one GPU)")
     args = ap.parse_args()
 
@@ -254,6 +302,8 @@ def main():
             out["zscore_regime"] = zs
         if train is not None:
             out["train_step"] = train
+        if world == 1 and not args.no_data_side:
+            out["data_side"] = data_side(dev, args.cohort, cpu=not args.no_cpu_baseline)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample)
         print(json.dumps(out))

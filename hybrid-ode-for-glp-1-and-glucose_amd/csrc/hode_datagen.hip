@@ -9,9 +9,8 @@
 //
 // K7 is a pure-ODE path (no MLP): ONE SUBJECT PER LANE (north_star's mapping), fp64, adaptive DP5(4) per lane with
 // free-running lanes (a lane does not wait for its neighbours at grid points).  ~1.2 kflop per RHS (three pow), 72 B
-// written per grid point: latency/VALU-bound, no LDS, no cross-lane traffic.  K8 is HBM-bound streaming: the table is
-// read three times (mean, centred second moment, emit -- the two-pass variance of numpy.std), outputs are written once,
-// coalesced.  Reductions are deterministic (fixed block partials, fixed-order final sum), so the same table always
+// written and 40 B of noise draws read per grid point: fp64-VALU-bound, no LDS, no cross-lane traffic.  K8 is HBM-bound streaming: the table is
+// read twice (shifted moments in one pass, then emit), outputs are written once, coalesced.  Reductions are deterministic (fixed block partials, fixed-order final sum), so the same table always
 // gives the same batches.
 #include "hode_kernels.h"
 
@@ -27,6 +26,15 @@ __constant__ double kDP[7][6] = {
     {9017.0 / 3168, -355.0 / 33, 46732.0 / 5247, 49.0 / 176, -5103.0 / 18656, 0},
     {35.0 / 384, 0, 500.0 / 1113, 125.0 / 192, -2187.0 / 6784, 11.0 / 84}};
 __constant__ double kDPE[7] = {-71.0 / 57600, 0, 71.0 / 16695, -71.0 / 1920, 17253.0 / 339200, -22.0 / 525, 1.0 / 40};
+
+// x^p for the Hill / power-law terms.  exp(p*log x) costs ~1/3 of ocml's correctly rounded pow (which carries log x
+// in double-double); its error is |p ln x| ulp <~ 10 ulp = 1e-15 here, far below the integration tolerance.
+// Same special values as numpy's float power on this path: 0^p = 0 (p > 0), x < 0 -> NaN, x^0 = 1.
+#ifdef HODE_4GI_EXACT_POW
+__device__ __forceinline__ double powr_(double x, double p) { return pow(x, p); }
+#else
+__device__ __forceinline__ double powr_(double x, double p) { return p == 0.0 ? 1.0 : exp(p * log(x)); }
+#endif
 
 // per-subject constants of generate4GI.py:94-116 (they depend on the subject's baselines only)
 struct Subject {
@@ -55,20 +63,20 @@ __device__ __forceinline__ void fourgi_rhs(const FourGIPar &p, const Subject &s,
                                            double *d)
 {
     const double Cglc = y[0] / p.VCglc, Cins = y[1] / p.VCins, Cglp = y[2] / p.VCglp, Cglg = y[3] / p.VCglg;
-    const double r = pow(Cglp / p.EC50_1, p.HILL_1);
+    const double r = powr_(Cglp / p.EC50_1, p.HILL_1);
     const double Sins = p.EMAX_1 * r / (1.0 + r);
     const double q = Cglg / p.EC50_4;
     const double Sglg = p.EMAX_4 * q / (1.0 + q);
     const double glg_on_glc = (1.0 + Sglg) / (1.0 + s.S0glg);
     const double p2 = Cglc >= s.Bglc ? 0.925 : (hv ? 0.327 : 0.0);
-    const double glc_on_glg = Cglc > 0.0 ? pow(s.Bglc / Cglc, p2) : 1.0;
+    const double glc_on_glg = Cglc > 0.0 ? powr_(s.Bglc / Cglc, p2) : 1.0;
     const double me = meal * 10.0;
     const bool fed = me > 0.0;
     const double fglp = fed ? p.FDGLP * me : 0.0, fgip = fed ? p.FDGIP * me : 0.0, fglg = fed ? p.FDGLG * me : 0.0;
     const double k27 = p.Qglc / p.VCglc, k72 = p.Qglc / p.VPglc, k612 = p.Qgip / p.VCgip, k126 = p.Qgip / p.VPgip;
     d[0] = meal + s.KINglc * glg_on_glc - k27 * y[0] + k72 * y[5] - (p.CLglc / p.VCglc) * y[0] -
            (p.CLglci * y[6] / p.VCglc) * y[0];
-    d[1] = s.KINins * (1.0 + Sins * pow(Cglc, p.GLCINS_S)) - (p.CLins / p.VCins) * y[1];
+    d[1] = s.KINins * (1.0 + Sins * powr_(Cglc, p.GLCINS_S)) - (p.CLins / p.VCins) * y[1];
     d[2] = s.KINglp * (1.0 + fglp) - p.VM_GLP * Cglp / (p.KM_GLP + Cglp);
     d[3] = s.KINglg * (1.0 + fglg) * glc_on_glg - (p.CLglg / p.VCglg) * y[3];
     d[4] = s.KINgip * (1.0 + fgip) - (p.CLgip / p.VCgip) * y[4] - k612 * y[4] + k126 * y[7];
@@ -116,7 +124,7 @@ __device__ inline void emit_row(const GenArgs &a, int b, int k, const double *y,
     for (int c = 0; c < 5; ++c) {
         double v = ok ? conc[c] : 0.0;
         if (a.z != nullptr && a.noise_cv != 0.0) {
-            const double zz = a.z[((size_t)b * 5 + c) * a.T + k];
+            const double zz = a.z[((size_t)k * 5 + c) * a.B + b];   // [T][5][B]: a wave reads 512 contiguous bytes
             v = add_noise(v, a.noise_cv * cvs[c], zz);   // generate4GI.py:239-243: cv = noise_cv * {1, 1.5, 1.5, 1.2, 1.3}
         }
         row[3 + c] = v;
@@ -263,8 +271,9 @@ int launch_4gi_rhs(hipStream_t s, int B, int hv, const FourGIPar &p, const doubl
 }
 
 // --------------------------------------------------------------------------------------------- K8: windows
-constexpr int kWinBlocks = 256;   // fixed number of partial sums => deterministic reduction
+constexpr int kWinBlocks = 1024;  // fixed number of partial sums => deterministic reduction, >= 4 workgroups per CU
 constexpr int kWinThreads = 256;
+static_assert(kWinBlocks * 12 * sizeof(double) <= HODE_4GI_SCRATCH_BYTES, "scratch holds one partial per block");
 
 __device__ inline double win_value(const WinArgs &a, int64_t row, int c)
 {
@@ -273,53 +282,60 @@ __device__ inline double win_value(const WinArgs &a, int64_t row, int c)
     return col >= 0 ? a.table[row * a.ncols + col] : (c == 5 ? 1.0 : 0.0);
 }
 
-// pass = 0: partial[block][c] = sum x ; pass = 1: partial[block][c] = sum (x - mean_c)^2   (numpy.std is two-pass)
-__global__ __launch_bounds__(kWinThreads) void win_moment_kernel(WinArgs a, int pass, const double *__restrict__ mean,
-                                                                 double *__restrict__ partial)
+// ONE pass over the windows for both moments: partial[block][c] = sum (x - ref_c), partial[block][6+c] = sum (x - ref_c)^2
+// with ref = the first window's first row.  Shifting by a sample of the data keeps sum^2/n small against the second
+// moment, so the variance is as accurate as numpy's two-pass value (to ~1e-15 relative) at one table read instead of two.
+__global__ __launch_bounds__(kWinThreads) void win_moment_kernel(WinArgs a, double *__restrict__ partial)
 {
-    __shared__ double red[kWinThreads / 64][6];
-    double acc[6] = {0, 0, 0, 0, 0, 0};
-    double mu[6] = {0, 0, 0, 0, 0, 0};
-    if (pass)
-        for (int c = 0; c < 6; ++c) mu[c] = mean[c];
+    __shared__ double red[kWinThreads / 64][12];
+    double s1[6] = {0, 0, 0, 0, 0, 0}, s2[6] = {0, 0, 0, 0, 0, 0}, ref[6];
+    const int64_t first = a.row0[0];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) ref[c] = win_value(a, first, c);
     const int64_t total = a.N * a.S;
-    // contiguous chunk per block, fixed by (N, S) alone
-    const int64_t per = (total + kWinBlocks - 1) / kWinBlocks;
+    const int64_t per = (total + kWinBlocks - 1) / kWinBlocks;   // contiguous chunk per block, fixed by (N, S) alone
     const int64_t lo = per * blockIdx.x, hi = lo + per < total ? lo + per : total;
     for (int64_t e = lo + threadIdx.x; e < hi; e += kWinThreads) {
         const int64_t row = a.row0[e / a.S] + e % a.S;
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
-            const double x = win_value(a, row, c) - mu[c];
-            acc[c] += pass ? x * x : x;
+            const double x = win_value(a, row, c) - ref[c];
+            s1[c] += x;
+            s2[c] += x * x;
         }
     }
 #pragma unroll
-    for (int c = 0; c < 6; ++c) {
-        double v = acc[c];
+    for (int c = 0; c < 12; ++c) {
+        double v = c < 6 ? s1[c % 6] : s2[c % 6];
         for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);   // butterfly: the same order in every run
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][c] = v;
     }
     __syncthreads();
-    if (threadIdx.x < 6) {
+    if (threadIdx.x < 12) {
         double v = 0.0;
         for (int wv = 0; wv < kWinThreads / 64; ++wv) v += red[wv][threadIdx.x];
-        partial[blockIdx.x * 6 + threadIdx.x] = v;
+        partial[blockIdx.x * 12 + threadIdx.x] = v;
     }
 }
 
-// pass 0: mean_std[c] = sum/count ; pass 1: mean_std[6+c] = sqrt(sum/count) + 1e-6   (train_hybrid.py:124-127)
-__global__ void win_finish_kernel(int pass, int64_t count, const double *__restrict__ partial, double *__restrict__ mean_std)
+// mean_c = ref_c + S1/n ; std_c = sqrt((S2 - S1^2/n)/n) + 1e-6   (train_hybrid.py:124-127)
+__global__ void win_finish_kernel(WinArgs a, const double *__restrict__ partial, double *__restrict__ mean_std)
 {
+    __shared__ double tot[12];
     const int c = threadIdx.x;
-    if (c >= 6) return;
-    double v = 0.0;
-    for (int blk = 0; blk < kWinBlocks; ++blk) v += partial[blk * 6 + c];
-    v /= (double)count;
-    if (pass == 0)
-        mean_std[c] = v;
-    else
-        mean_std[6 + c] = sqrt(v) + 1e-6;
+    if (c < 12) {
+        double v = 0.0;
+        for (int blk = 0; blk < kWinBlocks; ++blk) v += partial[blk * 12 + c];
+        tot[c] = v;
+    }
+    __syncthreads();
+    if (c < 6) {
+        const double n = (double)(a.N * a.S);
+        const double ref = win_value(a, a.row0[0], c);
+        const double var = (tot[6 + c] - tot[c] * tot[c] / n) / n;
+        mean_std[c] = ref + tot[c] / n;
+        mean_std[6 + c] = sqrt(var > 0.0 ? var : 0.0) + 1e-6;
+    }
 }
 
 __global__ void win_identity_kernel(double *mean_std)
@@ -357,10 +373,8 @@ int launch_4gi_windows(hipStream_t s, const WinArgs &a, int normalize, double *m
     }
     double *partial = (double *)scratch;
     if (normalize) {
-        for (int pass = 0; pass < 2; ++pass) {
-            hipLaunchKernelGGL(win_moment_kernel, dim3(kWinBlocks), dim3(kWinThreads), 0, s, a, pass, mean_std, partial);
-            hipLaunchKernelGGL(win_finish_kernel, dim3(1), dim3(64), 0, s, pass, total, partial, mean_std);
-        }
+        hipLaunchKernelGGL(win_moment_kernel, dim3(kWinBlocks), dim3(kWinThreads), 0, s, a, partial);
+        hipLaunchKernelGGL(win_finish_kernel, dim3(1), dim3(64), 0, s, a, partial, mean_std);
     } else {
         hipLaunchKernelGGL(win_identity_kernel, dim3(1), dim3(64), 0, s, mean_std);
     }

@@ -254,7 +254,7 @@ def mse_fwd_bwd(y, obs, scale, loss_sum=None, want_grad=True):
 
 # --------------------------------------------------------------------------------------------- data side
 FOURGI_NPAR = 26
-FOURGI_SCRATCH_BYTES = 16384
+FOURGI_SCRATCH_BYTES = 98304
 FOURGI_COLUMNS = ["subject_id", "time_hours", "time_minutes", "glucose_mmol_L", "insulin_pmol_L", "glp1_pmol_L",
                   "glucagon_pmol_L", "gip_pmol_L", "meal_indicator"]
 
@@ -283,8 +283,9 @@ def _par_host(par):
 
 
 def fourgi_generate(bsl, T, interval_min, meal_time, meal_size, patient_type="T2DM", par=None, z=None, noise_cv=0.0,
-                    subject0=0, rtol=1e-10, atol=1e-12, max_steps=100000):
-    """K7.  bsl[B,5] (device, fp64) -> (table[B*T,9] fp64, status[B] int32).  meal_time/meal_size: [n] or [B,n]."""
+                    subject0=0, rtol=1e-10, atol=1e-12, max_steps=100000, z_tcb=None):
+    """K7.  bsl[B,5] (device, fp64) -> (table[B*T,9] fp64, status[B] int32).  meal_time/meal_size: [n] or [B,n].
+    Noise draws: z[B,5,T] (numpy-stream order, transposed here) or z_tcb[T,5,B] (the kernel's layout, used as is)."""
     _need_gpu(bsl)
     dev = bsl.device
     bsl = bsl.to(torch.float64).contiguous().view(-1, 5)
@@ -295,9 +296,14 @@ def fourgi_generate(bsl, T, interval_min, meal_time, meal_size, patient_type="T2
         raise HodeError(f"meal_time / meal_size must both be [n_meals] or [B,n_meals], got {tuple(mt.shape)} / {tuple(ms.shape)}")
     n_meals = mt.shape[-1]
     if z is not None:
-        z = z.to(device=dev, dtype=torch.float64).contiguous()
+        # z[B,5,T] is the order FourGIModel.generate_dataset consumes numpy's stream in; the kernel wants [T,5,B]
         if tuple(z.shape) != (B, 5, T):
             raise HodeError(f"z must be [B,5,T]=({B},5,{T}), got {tuple(z.shape)}")
+        z = z.to(device=dev, dtype=torch.float64).permute(2, 1, 0).contiguous()
+    elif z_tcb is not None:
+        if tuple(z_tcb.shape) != (T, 5, B):
+            raise HodeError(f"z_tcb must be [T,5,B]=({T},5,{B}), got {tuple(z_tcb.shape)}")
+        z = z_tcb.to(device=dev, dtype=torch.float64).contiguous()
     table = torch.empty(B * T, 9, dtype=torch.float64, device=dev)
     status = torch.empty(B, dtype=torch.int32, device=dev)
     _check(load().hode_4gi_generate_f64(

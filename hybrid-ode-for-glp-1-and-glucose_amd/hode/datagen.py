@@ -67,9 +67,9 @@ class FourGIModel:
                             torch.tensor([float(meal_input)], dtype=torch.float64, device=dev), self.patient_type, self._par())
         return d[0].tolist()
 
-    def _tables(self, bsl, T, interval, meal_times, meal_sizes, z=None, noise_cv=0.0, subject0=0):
+    def _tables(self, bsl, T, interval, meal_times, meal_sizes, z=None, noise_cv=0.0, subject0=0, z_tcb=None):
         return capi.fourgi_generate(bsl, T, float(interval), meal_times, meal_sizes, self.patient_type, self._par(), z=z,
-                                    noise_cv=float(noise_cv), subject0=subject0, rtol=self.rtol, atol=self.atol)
+                                    noise_cv=float(noise_cv), subject0=subject0, rtol=self.rtol, atol=self.atol, z_tcb=z_tcb)
 
     def simulate(self, duration_hours=5, sampling_interval_min=5, meal_times=[], meal_sizes=[]):
         """-> (t_hours, glucose, insulin, glp1, glucagon, gip) numpy arrays, generate4GI.py:159-212."""
@@ -114,8 +114,8 @@ class FourGIModel:
         base = torch.tensor(self._bsl(), dtype=torch.float64, device=dev)
         cv = torch.tensor(_BSL_CV, dtype=torch.float64, device=dev)
         bsl = base * (1.0 + cv * torch.randn(n_subjects, 5, dtype=torch.float64, device=dev, generator=generator))
-        z = torch.randn(n_subjects, 5, T, dtype=torch.float64, device=dev, generator=generator) if noise_cv else None
-        return self._tables(bsl, T, sampling_interval_min, meal_times, meal_sizes, z=z, noise_cv=noise_cv, subject0=subject0)
+        z = torch.randn(T, 5, n_subjects, dtype=torch.float64, device=dev, generator=generator) if noise_cv else None
+        return self._tables(bsl, T, sampling_interval_min, meal_times, meal_sizes, z_tcb=z, noise_cv=noise_cv, subject0=subject0)
 
 
 class _Sequences:

@@ -147,7 +147,7 @@ int hode_selftest_xlane(void *stream, int32_t *out);
 #define HODE_4GI_HV 1
 #define HODE_4GI_TABLE_COLS 9  /* subject_id time_hours time_minutes glucose_mmol_L insulin_pmol_L glp1_pmol_L
                                   glucagon_pmol_L gip_pmol_L meal_indicator  (data/generate4GI.py:246-257) */
-#define HODE_4GI_SCRATCH_BYTES 16384
+#define HODE_4GI_SCRATCH_BYTES 98304
 
 /* the reference's parameter set (data/generate4GI.py:15-64) for a patient type -> par[HODE_4GI_NPAR] (HOST memory) */
 int hode_4gi_default_params(int patient_type, double *par_host);
@@ -158,8 +158,9 @@ int hode_4gi_default_params(int patient_type, double *par_host);
  *      T grid points at k*interval_min minutes; bsl[B,5] = the subject's baselines (glucose, insulin, GLP-1, glucagon,
  *      GIP); meals: meal_time/meal_size [n_meals] shared by all subjects (meals_per_subject = 0) or [B,n_meals];
  *      par_host: HOST pointer to HODE_4GI_NPAR doubles or NULL (= hode_4gi_default_params(patient_type));
- *      z[B,5,T]: standard-normal draws for the measurement noise (order glucose, insulin, glp1, glucagon, gip = the
- *      order generate_dataset consumes numpy's global stream) or NULL / noise_cv = 0 for the clean solution;
+ *      z[T,5,B]: standard-normal draws for the measurement noise (biomarker order glucose, insulin, glp1, glucagon,
+ *      gip; subject index fastest so that a wavefront reads contiguous memory) or NULL / noise_cv = 0 for the clean
+ *      solution;
  *      table[B*T, 9] written, subject ids start at subject0; status[B] (may be NULL) as in hode_solve_fwd.          */
 int hode_4gi_generate_f64(void *stream, int B, int T, double interval_min, int patient_type, const double *par_host,
                           const double *bsl, int n_meals, const double *meal_time, const double *meal_size,
@@ -174,7 +175,7 @@ int hode_4gi_rhs_f64(void *stream, int B, int patient_type, const double *par_ho
  *      table[rows, ncols] fp64 row-major; col_* = column indices (col_ge / col_ffa / col_meal / col_tvns may be -1:
  *      0, 1, 0, 0 as in :76-91); time = table[:, col_time] / time_div (60 for time_minutes, :93-94);
  *      row0[N] (device int64) = first table row of every window (subject by subject, start += stride, :105-121);
- *      normalize != 0: mean/std over ALL window rows (overlaps counted as often as they occur, numpy two-pass std,
+ *      normalize != 0: mean/std over ALL window rows (overlaps counted as often as they occur, population std
  *      + 1e-6; :124-127), else mean 0 / std 1.  Written: states[N,S,6] fp32 (observations; initial_state = [:,0]),
  *      meal[N,S], tvns[N,S], time[N,S] fp32, mean_std[12] fp64 (6 means, 6 stds).
  *      scratch: HODE_4GI_SCRATCH_BYTES of device memory.  Deterministic (no atomics).                              */

@@ -199,10 +199,10 @@ def test_largest_cohort_generate_window_train():
     bsl = torch.tensor([7.0, 50.0, 10.0, 25.0, 20.0], dtype=torch.float64, device=DEV) * (
         1.0 + torch.tensor([0.1, 0.15, 0.15, 0.15, 0.15], dtype=torch.float64, device=DEV)
         * torch.randn(B, 5, dtype=torch.float64, device=DEV, generator=gen2))
-    z = torch.randn(B, 5, T, dtype=torch.float64, device=DEV, generator=gen2)
+    z = torch.randn(T, 5, B, dtype=torch.float64, device=DEV, generator=gen2)
     import hode
     lo, hi = 40000, 40000 + 8192
-    part, _ = hode.capi.fourgi_generate(bsl[lo:hi], T, 5.0, [0.5, 2.5], [75, 50], z=z[lo:hi], noise_cv=0.1, subject0=lo)
+    part, _ = hode.capi.fourgi_generate(bsl[lo:hi], T, 5.0, [0.5, 2.5], [75, 50], z_tcb=z[:, :, lo:hi], noise_cv=0.1, subject0=lo)
     assert torch.equal(part, table[lo * T:hi * T])
     ds = GlucoseDataset(table, sequence_length=31, stride=15)
     assert len(ds) == B * 3

@@ -24,7 +24,7 @@ rows = list(csv.DictReader(open(stats[0])))
 with open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w") as f:
     f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --train-steps 2 --no-cpu-baseline\n")
     f.write("kernel,calls,total_ns,avg_ns,pct,min_ns,max_ns\n")
-    for r in rows[:12]:
+    for r in rows[:18]:
         f.write(f"\"{short(r['Name'])[:90]}\",{r['Calls']},{r['TotalDurationNs']},{float(r['AverageNs']):.0f},{r['Percentage']},{r['MinNs']},{r['MaxNs']}\n")
 
 pmc = collections.defaultdict(dict)
@@ -54,6 +54,9 @@ for k, d in pmc.items():
             traffic["solve_fwd_tape_hbm_bytes_per_launch"] = d["hbm_bytes_per_launch_corrected"]
         if "solve_bwd" in k:
             traffic["solve_bwd_hbm_bytes_per_launch"] = d["hbm_bytes_per_launch_corrected"]
+        for key in ("fourgi_generate", "win_moment", "win_emit"):      # data side (bench.py "data_side" leg)
+            if key in k:
+                traffic[f"{key}_hbm_bytes_per_launch"] = d["hbm_bytes_per_launch_corrected"]
 json.dump(out, open(os.path.join(dst, f"{tag}_pmc.json"), "w"), indent=1)
 traffic["source"] = f"profiles/{tag}_pmc.json (2*FETCH_SIZE + WRITE_SIZE) KiB, B=4096 T=241 fp32"
 json.dump(traffic, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
