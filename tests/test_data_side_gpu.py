@@ -215,3 +215,92 @@ def test_largest_cohort_generate_window_train():
     with torch.no_grad():
         pred = model(b["initial_state"][:4096], b["time_points"][0], {k: u[:4096] for k, u in b["external_inputs"].items()})
     assert pred.shape == (4096, 31, 6)
+
+
+# ---- the reference's tests/test_training.py:22-227 restated with the device dataset ---------------------------------
+def _reference_style_csv(path, n_subjects, n_timepoints):
+    """The synthetic frame of the reference's tests (sinusoids + noise, meals at 30 / 90 / 150 min, no gip column)."""
+    import pandas as pd
+    rows = []
+    for sid in range(n_subjects):
+        th = np.linspace(0, 5, n_timepoints)
+        cols = [5.0 + 2.0 * np.sin(th) + 0.5 * np.random.randn(n_timepoints),
+                100.0 + 50.0 * np.sin(th + 0.5) + 10.0 * np.random.randn(n_timepoints),
+                50.0 + 10.0 * np.sin(th + 1.0) + 5.0 * np.random.randn(n_timepoints),
+                20.0 + 10.0 * np.sin(th + 1.5) + 2.0 * np.random.randn(n_timepoints)]
+        meal = np.zeros(n_timepoints)
+        for mt in (30, 90, 150):
+            k = int(mt / 300 * n_timepoints)
+            if k < n_timepoints:
+                meal[k] = 1.0
+        for i in range(n_timepoints):
+            rows.append({"subject_id": sid, "time_hours": th[i], "time_minutes": th[i] * 60, "glucose_mmol_L": cols[0][i],
+                         "insulin_pmol_L": cols[1][i], "glucagon_pmol_L": cols[2][i], "glp1_pmol_L": cols[3][i],
+                         "meal_indicator": meal[i]})
+    pd.DataFrame(rows).to_csv(path, index=False)
+
+
+def _to_device(batch, device):
+    for key in batch:                                    # train_hybrid.py:238-246
+        if isinstance(batch[key], torch.Tensor):
+            batch[key] = batch[key].to(device)
+        elif isinstance(batch[key], dict):
+            for k, v in batch[key].items():
+                batch[key][k] = v.to(device)
+    return batch
+
+
+def test_reference_dataset_creation_restated(tmp_path):
+    from hode.datagen import GlucoseDataset
+    torch.manual_seed(0)
+    np.random.seed(0)
+    path = str(tmp_path / "d.csv")
+    _reference_style_csv(path, 3, 100)
+    ds = GlucoseDataset(path, sequence_length=20, stride=10, normalize=True)
+    assert len(ds) == 3 * 9 and len(ds.state_cols) == 6
+    item = ds[0]
+    assert {"initial_state", "observations", "time_points", "external_inputs"} <= set(item)
+    assert item["initial_state"].shape == (6,) and item["observations"].shape == (20, 6) and item["time_points"].shape == (20,)
+    assert not item["observations"].is_cuda                     # items are host tensors, as DataLoader workers expect
+    with pytest.raises(ValueError):
+        GlucoseDataset(str(tmp_path / "d.txt"))
+
+
+def test_reference_mini_training_and_validation_restated(tmp_path):
+    """train_epoch / validate (train_hybrid.py:225-302) over DataLoader(Subset(GlucoseDataset)) exactly as
+    tests/test_training.py:104-227 drives them; writer / tqdm left out."""
+    from torch.utils.data import DataLoader, Subset
+    from hode.datagen import GlucoseDataset
+    from models.hybrid_ode_nn import HybridODENN
+    torch.manual_seed(0)
+    np.random.seed(0)
+    path = str(tmp_path / "d.csv")
+    _reference_style_csv(path, 2, 100)
+    ds = GlucoseDataset(path, sequence_length=20, stride=10)
+    loader = DataLoader(Subset(ds, list(range(min(10, len(ds))))), batch_size=2, shuffle=True)
+    device = torch.device("cuda")
+    model = HybridODENN(nn_hidden=16, nn_layers=2, use_variational=False, device=device)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    before = {n: p.clone() for n, p in model.named_parameters()}
+    model.train()
+    total = 0.0
+    for batch in loader:
+        loss = model.loss(_to_device(batch, device), lambda1=0.5, lambda2=0.1, use_physics_loss=True)
+        opt.zero_grad()
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 5.0)
+        opt.step()
+        total += loss.item()
+    train_loss = total / len(loader)
+    assert isinstance(train_loss, float) and train_loss > 0 and not np.isnan(train_loss)
+    assert any(not torch.allclose(p, before[n], atol=1e-6) for n, p in model.named_parameters())
+    # validation (:278-302)
+    _reference_style_csv(path, 2, 50)
+    val = DataLoader(GlucoseDataset(path, sequence_length=20, stride=20), batch_size=2, shuffle=False)
+    model.eval()
+    vt = 0.0
+    with torch.no_grad():
+        for batch in val:
+            vt += model.loss(_to_device(batch, device), lambda1=0.5, lambda2=0.1, use_physics_loss=True).item()
+    val_loss = vt / len(val)
+    assert isinstance(val_loss, float) and val_loss > 0 and not np.isnan(val_loss)
