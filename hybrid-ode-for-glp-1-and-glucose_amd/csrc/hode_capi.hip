@@ -249,6 +249,7 @@ int hode_4gi_windows_f32(void *stream, const double *table, int ncols, int col_t
                          float *meal, float *tvns, float *time, double *mean_std, void *scratch)
 {
     if (N < 0 || S < 1 || ncols < 1 || !mean_std || !(time_div != 0.0)) return HODE_EINVAL;
+    if (normalize < HODE_4GI_NORM_NONE || normalize > HODE_4GI_NORM_GIVEN) return HODE_EINVAL;
     const int need[5] = {col_time, col_glucose, col_insulin, col_glucagon, col_glp1};
     for (int c : need)
         if (c < 0 || c >= ncols) return HODE_EINVAL;
@@ -262,6 +263,24 @@ int hode_4gi_windows_f32(void *stream, const double *table, int ncols, int col_t
     a.col_state[4] = col_ge; a.col_state[5] = col_ffa;
     a.time_div = time_div; a.row0 = row0; a.N = N; a.S = S; a.states = states; a.meal = meal; a.tvns = tvns; a.time = time;
     return launch_4gi_windows((hipStream_t)stream, a, normalize, mean_std, scratch);
+}
+
+int hode_4gi_window_moments_f64(void *stream, const double *table, int ncols, int col_glucose, int col_insulin,
+                                int col_glucagon, int col_glp1, int col_ge, int col_ffa, const int64_t *row0, int64_t N,
+                                int64_t S, double *moments, void *scratch)
+{
+    if (N < 0 || S < 1 || ncols < 1 || !moments) return HODE_EINVAL;
+    const int need[4] = {col_glucose, col_insulin, col_glucagon, col_glp1};
+    for (int c : need)
+        if (c < 0 || c >= ncols) return HODE_EINVAL;
+    if (col_ge < -1 || col_ge >= ncols || col_ffa < -1 || col_ffa >= ncols) return HODE_EINVAL;
+    if (N > 0 && (!table || !row0 || !scratch)) return HODE_EINVAL;
+    WinArgs a{};
+    a.table = table; a.ncols = ncols; a.col_time = 0; a.col_meal = -1; a.col_tvns = -1;
+    a.col_state[0] = col_glucose; a.col_state[1] = col_insulin; a.col_state[2] = col_glucagon; a.col_state[3] = col_glp1;
+    a.col_state[4] = col_ge; a.col_state[5] = col_ffa;
+    a.time_div = 1.0; a.row0 = row0; a.N = N; a.S = S;
+    return launch_4gi_window_moments((hipStream_t)stream, a, moments, scratch);
 }
 
 }  // extern "C"

@@ -318,23 +318,33 @@ __global__ __launch_bounds__(kWinThreads) void win_moment_kernel(WinArgs a, doub
     }
 }
 
-// mean_c = ref_c + S1/n ; std_c = sqrt((S2 - S1^2/n)/n) + 1e-6   (train_hybrid.py:124-127)
-__global__ void win_finish_kernel(WinArgs a, const double *__restrict__ partial, double *__restrict__ mean_std)
+// mean_c = ref_c + S1/n ; std_c = sqrt((S2 - S1^2/n)/n) + 1e-6   (train_hybrid.py:124-127).  12 waves, one per sum.
+// moments != 0: write {n, mean[6], M2[6]} (M2 = sum of squared deviations) instead -- the mergeable form a multi-GPU
+// dataset exchanges (13 doubles per rank, combined with Chan's formula on the host).
+__global__ __launch_bounds__(768) void win_finish_kernel(WinArgs a, const double *__restrict__ partial,
+                                                         double *__restrict__ mean_std, int moments)
 {
     __shared__ double tot[12];
-    const int c = threadIdx.x;
-    if (c < 12) {
-        double v = 0.0;
-        for (int blk = 0; blk < kWinBlocks; ++blk) v += partial[blk * 12 + c];
-        tot[c] = v;
-    }
+    const int q = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double v = 0.0;
+    for (int blk = lane; blk < kWinBlocks; blk += 64) v += partial[blk * 12 + q];   // fixed order per lane
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (lane == 0) tot[q] = v;
     __syncthreads();
+    const int c = threadIdx.x;
     if (c < 6) {
         const double n = (double)(a.N * a.S);
         const double ref = win_value(a, a.row0[0], c);
-        const double var = (tot[6 + c] - tot[c] * tot[c] / n) / n;
-        mean_std[c] = ref + tot[c] / n;
-        mean_std[6 + c] = sqrt(var > 0.0 ? var : 0.0) + 1e-6;
+        const double m2 = tot[6 + c] - tot[c] * tot[c] / n;
+        if (moments) {
+            if (c == 0) mean_std[0] = n;
+            mean_std[1 + c] = ref + tot[c] / n;
+            mean_std[7 + c] = m2 > 0.0 ? m2 : 0.0;
+        } else {
+            const double var = m2 / n;
+            mean_std[c] = ref + tot[c] / n;
+            mean_std[6 + c] = sqrt(var > 0.0 ? var : 0.0) + 1e-6;
+        }
     }
 }
 
@@ -372,15 +382,33 @@ int launch_4gi_windows(hipStream_t s, const WinArgs &a, int normalize, double *m
         return hipGetLastError() == hipSuccess ? HODE_OK : HODE_ELAUNCH;
     }
     double *partial = (double *)scratch;
-    if (normalize) {
+    if (normalize == HODE_4GI_NORM_GIVEN) {
+        // mean_std already holds the statistics (e.g. combined over the ranks of a sharded dataset)
+    } else if (normalize) {
         hipLaunchKernelGGL(win_moment_kernel, dim3(kWinBlocks), dim3(kWinThreads), 0, s, a, partial);
-        hipLaunchKernelGGL(win_finish_kernel, dim3(1), dim3(64), 0, s, a, partial, mean_std);
+        hipLaunchKernelGGL(win_finish_kernel, dim3(1), dim3(768), 0, s, a, partial, mean_std, 0);
     } else {
         hipLaunchKernelGGL(win_identity_kernel, dim3(1), dim3(64), 0, s, mean_std);
     }
     const int64_t blocks = (total + 255) / 256;
     if (blocks > 0x7fffffff) return HODE_EUNSUPPORTED;
     hipLaunchKernelGGL(win_emit_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a, mean_std);
+    return hipGetLastError() == hipSuccess ? HODE_OK : HODE_ELAUNCH;
+}
+
+__global__ void win_zero_moments_kernel(double *m)
+{
+    if (threadIdx.x < 13) m[threadIdx.x] = 0.0;
+}
+
+int launch_4gi_window_moments(hipStream_t s, const WinArgs &a, double *moments, void *scratch)
+{
+    if (a.N * a.S <= 0) {
+        hipLaunchKernelGGL(win_zero_moments_kernel, dim3(1), dim3(64), 0, s, moments);
+        return hipGetLastError() == hipSuccess ? HODE_OK : HODE_ELAUNCH;
+    }
+    hipLaunchKernelGGL(win_moment_kernel, dim3(kWinBlocks), dim3(kWinThreads), 0, s, a, (double *)scratch);
+    hipLaunchKernelGGL(win_finish_kernel, dim3(1), dim3(768), 0, s, a, (const double *)scratch, moments, 1);
     return hipGetLastError() == hipSuccess ? HODE_OK : HODE_ELAUNCH;
 }
 

@@ -78,6 +78,7 @@ int launch_4gi_generate(hipStream_t s, const GenArgs &a);
 int launch_4gi_rhs(hipStream_t s, int B, int hv, const FourGIPar &p, const double *bsl, const double *y, const double *meal,
                    double *d);
 int launch_4gi_windows(hipStream_t s, const WinArgs &a, int normalize, double *mean_std, void *scratch);
+int launch_4gi_window_moments(hipStream_t s, const WinArgs &a, double *moments, void *scratch);
 
 // tape = entries | interval indices | (256-byte aligned) stage tape
 inline size_t tape_seg_offset(int B, int max_steps, size_t elem) { return (size_t)B * max_steps * 8 * elem; }

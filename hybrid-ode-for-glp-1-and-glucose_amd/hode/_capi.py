@@ -21,7 +21,7 @@ SYMBOLS = ["hode_version", "hode_nn_param_count", "hode_tape_bytes", "hode_rhs_f
            "hode_rhs_bwd_f32", "hode_rhs_bwd_f64", "hode_solve_fwd_f32", "hode_solve_fwd_f64",
            "hode_solve_bwd_f32", "hode_solve_bwd_f64", "hode_adam_step_f32", "hode_mse_fwd_bwd_f32",
            "hode_selftest_xlane", "hode_4gi_default_params", "hode_4gi_generate_f64", "hode_4gi_rhs_f64",
-           "hode_4gi_windows_f32"]
+           "hode_4gi_windows_f32", "hode_4gi_window_moments_f64"]
 
 
 class HodeError(RuntimeError):
@@ -328,7 +328,46 @@ def fourgi_rhs(bsl, y, meal, patient_type="T2DM", par=None):
     return d
 
 
-def fourgi_windows(table, cols, time_div, row0, seq_len, normalize=True):
+def fourgi_window_moments(table, cols, row0, seq_len, check_bounds=True):
+    """Mergeable statistics of one shard's windows -> tensor[13] = {count, mean[6], M2[6]} on the device."""
+    _need_gpu(table)
+    dev = table.device
+    if table.dtype != torch.float64 or table.dim() != 2:
+        raise HodeError("table must be a 2-D float64 tensor")
+    table = table.contiguous()
+    row0 = row0.to(device=dev, dtype=torch.int64).contiguous()
+    N, S = row0.numel(), int(seq_len)
+    if check_bounds and N and (int(row0.min()) < 0 or int(row0.max()) + S > table.shape[0]):
+        raise HodeError("window outside the table")
+    mom = torch.empty(13, dtype=torch.float64, device=dev)
+    scratch = torch.empty(FOURGI_SCRATCH_BYTES, dtype=torch.uint8, device=dev)
+    g = lambda k: C.c_int(int(cols.get(k, -1)))
+    _check(load().hode_4gi_window_moments_f64(_stream(), _ptr(table), C.c_int(table.shape[1]), g("glucose"), g("insulin"),
+                                              g("glucagon"), g("glp1"), g("ge"), g("ffa"), _ptr(row0), C.c_int64(N),
+                                              C.c_int64(S), _ptr(mom), _ptr(scratch)), "hode_4gi_window_moments_f64")
+    return mom
+
+
+def combine_moments(moments):
+    """moments[R,13] (one row per shard, rank order) -> (mean[6], std[6]) float64 CPU tensors: Chan's pairwise merge,
+    applied in rank order so that every rank gets the same bits; std = sqrt(M2 / n) + 1e-6 (train_hybrid.py:124-127)."""
+    m = torch.as_tensor(moments, dtype=torch.float64).cpu().reshape(-1, 13)
+    n, mean, m2 = 0.0, torch.zeros(6, dtype=torch.float64), torch.zeros(6, dtype=torch.float64)
+    for r in range(m.shape[0]):
+        nb = float(m[r, 0])
+        if nb == 0:
+            continue
+        d = m[r, 1:7] - mean
+        tot = n + nb
+        m2 = m2 + m[r, 7:13] + d * d * (n * nb / tot)
+        mean = mean + d * (nb / tot)
+        n = tot
+    if n == 0:
+        return torch.zeros(6, dtype=torch.float64), torch.ones(6, dtype=torch.float64)
+    return mean, torch.sqrt(m2 / n) + 1e-6
+
+
+def fourgi_windows(table, cols, time_div, row0, seq_len, normalize=True, mean_std=None, check_bounds=True):
     """K8.  table[rows,ncols] fp64 (device); cols: dict time/glucose/insulin/glucagon/glp1 (+ optional ge/ffa/meal/tvns)
     -> column index; row0[N] int64 (device).  -> states[N,S,6], meal[N,S], tvns[N,S], time[N,S] (fp32), mean_std[12] (fp64)."""
     _need_gpu(table)
@@ -338,16 +377,25 @@ def fourgi_windows(table, cols, time_div, row0, seq_len, normalize=True):
     table = table.contiguous()
     row0 = row0.to(device=dev, dtype=torch.int64).contiguous()
     N, S = row0.numel(), int(seq_len)
-    if N and (int(row0.min()) < 0 or int(row0.max()) + S > table.shape[0]):
-        raise HodeError("window outside the table")     # checked on the host BEFORE the launch
+    # checked on the host BEFORE the launch (two device reductions + a sync); callers that built row0 from the table's
+    # own subject ranges (GlucoseDataset) pass check_bounds=False
+    if check_bounds and N and (int(row0.min()) < 0 or int(row0.max()) + S > table.shape[0]):
+        raise HodeError("window outside the table")
     states = torch.empty(N, S, 6, dtype=torch.float32, device=dev)
     meal, tvns, time = (torch.empty(N, S, dtype=torch.float32, device=dev) for _ in range(3))
-    mean_std = torch.empty(12, dtype=torch.float64, device=dev)
+    if mean_std is not None:                            # statistics given (HODE_4GI_NORM_GIVEN)
+        mean_std = torch.as_tensor(mean_std, dtype=torch.float64).to(dev).contiguous().clone()
+        if mean_std.numel() != 12:
+            raise HodeError("mean_std must hold 6 means and 6 stds")
+        normalize = 2
+    else:
+        mean_std = torch.empty(12, dtype=torch.float64, device=dev)
+        normalize = int(bool(normalize))
     scratch = torch.empty(FOURGI_SCRATCH_BYTES, dtype=torch.uint8, device=dev)
     g = lambda k: C.c_int(int(cols.get(k, -1)))
     _check(load().hode_4gi_windows_f32(
         _stream(), _ptr(table), C.c_int(table.shape[1]), g("time"), C.c_double(time_div), g("glucose"), g("insulin"),
         g("glucagon"), g("glp1"), g("ge"), g("ffa"), g("meal"), g("tvns"), _ptr(row0), C.c_int64(N), C.c_int64(S),
-        C.c_int(int(bool(normalize))), _ptr(states), _ptr(meal), _ptr(tvns), _ptr(time), _ptr(mean_std), _ptr(scratch)),
+        C.c_int(normalize), _ptr(states), _ptr(meal), _ptr(tvns), _ptr(time), _ptr(mean_std), _ptr(scratch)),
         "hode_4gi_windows_f32")
     return states, meal, tvns, time, mean_std

@@ -118,6 +118,18 @@ class FourGIModel:
         return self._tables(bsl, T, sampling_interval_min, meal_times, meal_sizes, z_tcb=z, noise_cv=noise_cv, subject0=subject0)
 
 
+def merge_moments_over_group(moments, group=None):
+    """All-gather one shard's {count, mean[6], M2[6]} over the process group and merge in rank order.
+    -> (mean[6], std[6]) float64 CPU tensors, identical on every rank.  13 doubles per rank: the only exchange the
+    sharded dataset needs (RCCL when the group's backend is "nccl"; staged through the host for gloo)."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    buf = moments if dist.get_backend(group) == "nccl" else moments.cpu()
+    out = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(out, buf, group=group)
+    return capi.combine_moments(torch.stack([o.cpu() for o in out]))
+
+
 class _Sequences:
     """Lazy stand-in for the reference's `dataset.sequences` list of dicts (train_hybrid.py:113-121): raw values."""
 
@@ -147,9 +159,11 @@ class _Sequences:
 
 
 class GlucoseDataset(torch.utils.data.Dataset):
-    def __init__(self, data_path, sequence_length=61, stride=30, normalize=True, device=None):
+    def __init__(self, data_path, sequence_length=61, stride=30, normalize=True, device=None, group=None):
         """data_path: '.csv' / '.parquet' file in the reference's column format (train_hybrid.py:64-69), or a device
-        table [rows, 9] from FourGIModel.generate_cohort, or a (table, column_names) pair."""
+        table [rows, 9] from FourGIModel.generate_cohort, or a (table, column_names) pair.
+        group: this process holds only a SHARD of the subjects (one process per GPU); pass the torch.distributed
+        process group (True = the default group) and the z-score statistics are those of the whole dataset."""
         self.sequence_length = sequence_length
         self.stride = stride
         self.normalize = normalize
@@ -193,8 +207,13 @@ class GlucoseDataset(torch.utils.data.Dataset):
         self._row0_host = np.concatenate(starts) if starts else np.zeros(0, np.int64)
         self._subject_of_window = owner
         row0 = torch.as_tensor(self._row0_host, device=dev)
+        given = None
+        if normalize and group is not None:
+            mom = capi.fourgi_window_moments(self._table, cols, row0, sequence_length, check_bounds=False)
+            given = torch.cat(merge_moments_over_group(mom, None if group is True else group))
         self._states, self._meal, self._tvns, self._time, ms = capi.fourgi_windows(self._table, cols, self._time_div, row0,
-                                                                                   sequence_length, normalize)
+                                                                                   sequence_length, normalize, mean_std=given,
+                                                                                   check_bounds=False)
         ms = ms.cpu().numpy()
         self.state_mean, self.state_std = ms[:6].copy(), ms[6:].copy()
         self.sequences = _Sequences(self)

@@ -148,6 +148,9 @@ int hode_selftest_xlane(void *stream, int32_t *out);
 #define HODE_4GI_TABLE_COLS 9  /* subject_id time_hours time_minutes glucose_mmol_L insulin_pmol_L glp1_pmol_L
                                   glucagon_pmol_L gip_pmol_L meal_indicator  (data/generate4GI.py:246-257) */
 #define HODE_4GI_SCRATCH_BYTES 98304
+#define HODE_4GI_NORM_NONE 0   /* mean 0 / std 1 */
+#define HODE_4GI_NORM_LOCAL 1  /* statistics of the windows passed in this call */
+#define HODE_4GI_NORM_GIVEN 2  /* mean_std[12] is an INPUT (statistics combined over the shards of a multi-GPU dataset) */
 
 /* the reference's parameter set (data/generate4GI.py:15-64) for a patient type -> par[HODE_4GI_NPAR] (HOST memory) */
 int hode_4gi_default_params(int patient_type, double *par_host);
@@ -175,14 +178,22 @@ int hode_4gi_rhs_f64(void *stream, int B, int patient_type, const double *par_ho
  *      table[rows, ncols] fp64 row-major; col_* = column indices (col_ge / col_ffa / col_meal / col_tvns may be -1:
  *      0, 1, 0, 0 as in :76-91); time = table[:, col_time] / time_div (60 for time_minutes, :93-94);
  *      row0[N] (device int64) = first table row of every window (subject by subject, start += stride, :105-121);
- *      normalize != 0: mean/std over ALL window rows (overlaps counted as often as they occur, population std
- *      + 1e-6; :124-127), else mean 0 / std 1.  Written: states[N,S,6] fp32 (observations; initial_state = [:,0]),
+ *      normalize = HODE_4GI_NORM_LOCAL: mean/std over ALL window rows (overlaps counted as often as they occur, population std
+ *      + 1e-6; :124-127), HODE_4GI_NORM_NONE: mean 0 / std 1, HODE_4GI_NORM_GIVEN: as found in mean_std.  Written: states[N,S,6] fp32 (observations; initial_state = [:,0]),
  *      meal[N,S], tvns[N,S], time[N,S] fp32, mean_std[12] fp64 (6 means, 6 stds).
  *      scratch: HODE_4GI_SCRATCH_BYTES of device memory.  Deterministic (no atomics).                              */
 int hode_4gi_windows_f32(void *stream, const double *table, int ncols, int col_time, double time_div, int col_glucose,
                          int col_insulin, int col_glucagon, int col_glp1, int col_ge, int col_ffa, int col_meal,
                          int col_tvns, const int64_t *row0, int64_t N, int64_t S, int normalize, float *states,
                          float *meal, float *tvns, float *time, double *mean_std, void *scratch);
+
+/* Mergeable statistics of the windows of ONE shard: moments[13] = {count, mean[6], M2[6]} (M2 = sum of squared
+ * deviations from the shard mean).  A dataset sharded over GPUs all-gathers these 13 doubles, merges them in rank
+ * order (Chan et al.: M2 = M2a + M2b + d^2 na nb / n), sets std = sqrt(M2/n) + 1e-6 and calls hode_4gi_windows_f32
+ * with HODE_4GI_NORM_GIVEN, so every rank normalises with the statistics of the whole dataset. */
+int hode_4gi_window_moments_f64(void *stream, const double *table, int ncols, int col_glucose, int col_insulin,
+                                int col_glucagon, int col_glp1, int col_ge, int col_ffa, const int64_t *row0, int64_t N,
+                                int64_t S, double *moments, void *scratch);
 
 #ifdef __cplusplus
 }

@@ -141,3 +141,65 @@ def test_4gi_argument_validation_without_gpu():
     assert w(*bad) == -1
     bad = list(args); bad[4] = C.c_double(0.0)
     assert w(*bad) == -1
+
+
+# ---- sharded dataset: merging the window statistics of the shards -------------------------------------------------
+def _np_moments(x):
+    """{count, mean[6], M2[6]} of the rows x[n,6] -- what hode_4gi_window_moments_f64 returns for one shard."""
+    if len(x) == 0:
+        return np.zeros(13)
+    m = x.mean(0)
+    return np.concatenate([[len(x)], m, ((x - m) ** 2).sum(0)])
+
+
+def test_combine_moments_equals_global_statistics():
+    import hode
+    rng = np.random.default_rng(0)
+    x = rng.normal([5, 100, 50, 20, 0, 1], [2, 50, 10, 10, 0, 0], size=(5000, 6))
+    for cuts in ([0, 5000], [0, 1, 5000], [0, 1200, 1200, 3100, 5000], [0, 0, 5000]):       # incl. empty shards
+        mom = np.stack([_np_moments(x[a:b]) for a, b in zip(cuts[:-1], cuts[1:])])
+        mean, std = hode.capi.combine_moments(mom)
+        np.testing.assert_allclose(mean.numpy(), x.mean(0), rtol=1e-13, atol=1e-15)
+        np.testing.assert_allclose(std.numpy(), x.std(0) + 1e-6, rtol=1e-12)
+    mean, std = hode.capi.combine_moments(np.zeros((3, 13)))
+    assert mean.tolist() == [0.0] * 6 and std.tolist() == [1.0] * 6
+
+
+def _merge_worker(rank, world, port, q):
+    import os
+    import torch
+    import torch.distributed as dist
+    from hode.datagen import merge_moments_over_group
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    x = np.random.default_rng(1).normal(50, 20, size=(901, 6))
+    lo, hi = [(0, 300), (300, 901)][rank] if world == 2 else [(0, 10), (10, 10), (10, 901)][rank]
+    mean, std = merge_moments_over_group(torch.tensor(_np_moments(x[lo:hi])))
+    q.put((rank, mean.numpy(), std.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_statistics_over_gloo(world):
+    """One process per shard, a single all_gather of 13 doubles: every rank ends with the statistics of the whole set."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_merge_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    x = np.random.default_rng(1).normal(50, 20, size=(901, 6))
+    for _, mean, std in res:
+        assert np.array_equal(mean, res[0][1]) and np.array_equal(std, res[0][2])          # bit-identical replicas
+        np.testing.assert_allclose(mean, x.mean(0), rtol=1e-13)
+        np.testing.assert_allclose(std, x.std(0) + 1e-6, rtol=1e-12)

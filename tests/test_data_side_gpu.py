@@ -304,3 +304,81 @@ def test_reference_mini_training_and_validation_restated(tmp_path):
             vt += model.loss(_to_device(batch, device), lambda1=0.5, lambda2=0.1, use_physics_loss=True).item()
     val_loss = vt / len(val)
     assert isinstance(val_loss, float) and val_loss > 0 and not np.isnan(val_loss)
+
+
+def test_k8_shard_moments_merge_to_the_global_statistics():
+    """Two shards of subjects (what two GPUs would hold): their moments merge to the statistics of the whole table,
+    and windows normalised with the merged statistics equal the single-GPU windows."""
+    import hode
+    from oracle import fourgi
+    rng = np.random.default_rng(4)
+    rows, S, stride = 61 * 40, 31, 15
+    tab = np.column_stack([np.repeat(np.arange(40), 61), rng.normal(0, 1, rows), np.tile(np.arange(61) * 5.0, 40)]
+                          + [rng.normal(m, sd, rows) for m, sd in ((7, 1), (200, 80), (900, 700), (25, 1), (25, 4))]
+                          + [(rng.uniform(size=rows) < 0.03).astype(float)])
+    cols = dict(time=2, glucose=3, insulin=4, glucagon=6, glp1=5, meal=8)
+    row0 = (np.arange(40)[:, None] * 61 + np.arange(0, 61 - S + 1, stride)[None, :]).reshape(-1)
+    full = hode.capi.fourgi_windows(_t(tab), cols, 60.0, _t(row0), S, True)
+    cut, wcut = 61 * 13, 13 * 3                                  # shard A: subjects 0-12, shard B: 13-39
+    ma = hode.capi.fourgi_window_moments(_t(tab[:cut]), cols, _t(row0[:wcut]), S)
+    mb = hode.capi.fourgi_window_moments(_t(tab[cut:]), cols, _t(row0[wcut:] - cut), S)
+    assert float(ma[0]) == wcut * S and float(mb[0]) == (len(row0) - wcut) * S
+    mean, std = hode.capi.combine_moments(torch.stack([ma, mb]))
+    np.testing.assert_allclose(torch.cat([mean, std]).numpy(), full[4].cpu().numpy(), rtol=1e-12)
+    a = hode.capi.fourgi_windows(_t(tab[:cut]), cols, 60.0, _t(row0[:wcut]), S, mean_std=torch.cat([mean, std]))
+    b = hode.capi.fourgi_windows(_t(tab[cut:]), cols, 60.0, _t(row0[wcut:] - cut), S, mean_std=torch.cat([mean, std]))
+    np.testing.assert_allclose(torch.cat([a[0], b[0]]).cpu().numpy(), full[0].cpu().numpy(), rtol=2e-7, atol=1e-7)
+    assert torch.equal(torch.cat([a[3], b[3]]), full[3]) and torch.equal(torch.cat([a[1], b[1]]), full[1])
+    # empty shard: zero moments, ignored by the merge
+    m0 = hode.capi.fourgi_window_moments(_t(tab[:61]), cols, torch.zeros(0, dtype=torch.int64, device=DEV), S)
+    assert m0.cpu().tolist() == [0.0] * 13
+
+
+def _sharded_dataset_worker(rank, world, port, path, q):
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)      # rehearsal backend: both ranks share cuda:0
+    import pandas as pd
+    from hode.datagen import GlucoseDataset
+    from hode.train import shard_bounds
+    df = pd.read_csv(path)
+    subs = sorted(df["subject_id"].unique())
+    lo, hi = shard_bounds(len(subs), rank, world)
+    shard = str(path) + f".rank{rank}.csv"
+    df[df["subject_id"].isin(subs[lo:hi])].to_csv(shard, index=False, float_format="%.17g")
+    ds = GlucoseDataset(shard, sequence_length=20, stride=10, group=True)
+    q.put((rank, ds.state_mean, ds.state_std, ds.batch(np.arange(len(ds)))["observations"].cpu().numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_k8_dataset_sharded_over_two_ranks(golden_dir, tmp_path):
+    """GlucoseDataset(group=...) in two processes, each holding half of the subjects of the reference's CSV: statistics
+    and windows equal the reference's single-process dataset (G9)."""
+    import socket
+    import pandas as pd
+    import torch.multiprocessing as mp
+    g = _g(golden_dir, "g9_windows_4gi_20_10.npz")
+    t = _g(golden_dir, "g9_4gi_dataset_table.npz")
+    path = str(tmp_path / "all.csv")
+    pd.DataFrame(t["table"], columns=list(t["columns"])).to_csv(path, index=False, float_format="%.17g")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sharded_dataset_worker, args=(r, 2, port, path, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda r: r[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for _, mean, std, _ in res:
+        assert np.array_equal(mean, res[0][1]) and np.array_equal(std, res[0][2])
+        np.testing.assert_allclose(mean, g["state_mean"], rtol=1e-12)
+        np.testing.assert_allclose(std, g["state_std"], rtol=1e-12)
+    obs = np.concatenate([res[0][3], res[1][3]])
+    np.testing.assert_allclose(obs, g["observations"], rtol=2e-7, atol=1e-7)
