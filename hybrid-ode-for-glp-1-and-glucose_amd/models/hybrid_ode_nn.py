@@ -64,15 +64,34 @@ class _RhsFn(torch.autograd.Function):
         return gx, gt, gnn, gode, None, None, None, None, None
 
 
+# Stage-tape budget of one autograd solve.  The adjoint reads 6*(L+1)*256 B per accepted step (2.3 MB per trajectory
+# for the 4x64 network at T = 241): 4 096 patients need 8.8 GiB, BASELINE config 5's 8 192 patients x 16 VI samples per
+# GPU would need 282 GiB.  Above the budget the forward runs WITHOUT a tape and the backward re-integrates the batch in
+# chunks that fit (forward-with-tape + adjoint per chunk, one tape buffer re-used): bounded memory for 1.3x the time.
+TAPE_BUDGET_BYTES = 64 << 30
+
+
+def _tape_steps(T, method):
+    return max(T - 1, 1) if method == hode.METHOD_RK4 else (T - 1) + max(32, (T - 1) // 4)
+
+
 class _SolveFn(torch.autograd.Function):
     """forward solve (K2+K3); backward = reverse-time discrete adjoint (K4)."""
 
     @staticmethod
     def forward(ctx, x0, nn_flat, ode_vec, t, meal, tvns, gd, H, L, method, rtol, atol, n_sets, info):
         need_tape = any(ctx.needs_input_grad[:3])
+        B, T = x0.shape[0], t.shape[-1]
+        steps = _tape_steps(T, method)
+        per_traj = hode.capi.tape_nbytes(1, steps, x0.element_size(), L)
+        ctx.chunked = need_tape and B * per_traj > TAPE_BUDGET_BYTES
+        # same accepted-step budget on both routes, so a chunked solve returns the same trajectories bit for bit
         sol = hode.solve_fwd(x0, t, meal, tvns, gd, ode_vec, nn_flat, H, L, method=method, rtol=rtol, atol=atol,
-                             n_sets=n_sets, want_tape=need_tape)
-        ctx.sol = sol if need_tape else None
+                             n_sets=n_sets, want_tape=need_tape and not ctx.chunked, max_steps=steps if need_tape else None)
+        ctx.sol = sol if need_tape and not ctx.chunked else None
+        if ctx.chunked:
+            ctx.args = (x0, nn_flat, ode_vec, t, meal, tvns, gd, H, L, method, rtol, atol, n_sets, steps,
+                        max(1, TAPE_BUDGET_BYTES // per_traj))
         info["status"], info["nsteps"], info["nfev"] = sol.status, sol.nsteps, sol.nfev
         return sol.y
 
@@ -80,8 +99,37 @@ class _SolveFn(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, gy):
         need = ctx.needs_input_grad
-        gx0, gnn, gode = hode.solve_bwd(ctx.sol, gy.contiguous(), want_gnn=need[1], want_gode=need[2])
-        ctx.sol = None
+        if not ctx.chunked:
+            gx0, gnn, gode = hode.solve_bwd(ctx.sol, gy.contiguous(), want_gnn=need[1], want_gode=need[2])
+            ctx.sol = None
+            return (gx0 if need[0] else None, gnn, gode) + (None,) * 11
+        x0, nn_flat, ode_vec, t, meal, tvns, gd, H, L, method, rtol, atol, n_sets, steps, cap = ctx.args
+        ctx.args = None
+        gy = gy.contiguous()
+        B, P = x0.shape[0], nn_flat.numel() // n_sets
+        G = B // n_sets                                   # trajectories per parameter set (contiguous groups)
+        gx0 = torch.empty_like(x0)
+        gnn = torch.zeros_like(nn_flat) if need[1] else None
+        gode = torch.zeros_like(ode_vec) if need[2] else None
+        # chunk = m whole parameter sets when a set fits the budget, else a slice of one set
+        if cap >= G:
+            m = min(n_sets, cap // G)
+            pieces = [(s * G, min(s + m, n_sets) * G, s, min(s + m, n_sets)) for s in range(0, n_sets, m)]
+        else:
+            pieces = [(s * G + a, s * G + min(a + cap, G), s, s + 1) for s in range(n_sets) for a in range(0, G, cap)]
+        tape = None
+        cut = lambda v, lo, hi: None if v is None else v[lo:hi]          # noqa: E731  ([B,T] and [B] inputs alike)
+        for lo, hi, s0, s1 in pieces:
+            sol = hode.solve_fwd(x0[lo:hi], t[lo:hi] if t.dim() == 2 else t, cut(meal, lo, hi), cut(tvns, lo, hi),
+                                 cut(gd, lo, hi), ode_vec[17 * s0:17 * s1], nn_flat[P * s0:P * s1], H, L, method=method,
+                                 rtol=rtol, atol=atol, n_sets=s1 - s0, want_tape=tape is None, tape=tape, max_steps=steps)
+            tape = sol.tape                                              # largest chunk first: later ones fit
+            g0, gn, go = hode.solve_bwd(sol, gy[lo:hi], want_gnn=need[1], want_gode=need[2])
+            gx0[lo:hi] = g0
+            if gn is not None:
+                gnn[P * s0:P * s1] += gn
+            if go is not None:
+                gode[17 * s0:17 * s1] += go
         return (gx0 if need[0] else None, gnn, gode) + (None,) * 11
 
 

@@ -392,3 +392,59 @@ def test_fused_train_step_matches_class_path(M, golden_dir):
     assert float((state.p - p_class).abs().max()) < 2e-6
     losses = [float(loss_f)] + [float(hode.train.train_step(state, compute, lr=1e-3, max_norm=5.0)) for _ in range(8)]
     assert losses[-1] < losses[0]
+
+
+def test_tape_budget_chunked_adjoint_equals_single_launch(M, golden_dir, monkeypatch):
+    """Above the stage-tape budget (BASELINE config 5: 8 192 patients x 16 samples per GPU would need 282 GiB) the
+    backward re-integrates the batch chunk by chunk.  Same trajectories bit for bit, same gradients up to the order of
+    the fp32 atomics -- for a plain batch, for whole-parameter-set chunks and for chunks inside one parameter set."""
+    import hode
+    import models.hybrid_ode_nn as HN
+    g = np.load(os.path.join(golden_dir, "g4_t61_pulses.npz"))
+    m = load_model(M, golden_dir, "cuda")
+    x0 = torch.tensor(g["x0"]).cuda().requires_grad_(True)
+    t, ext = torch.tensor(g["t"]).cuda(), {"meal": torch.tensor(g["meal"]).cuda(), "tVNS": torch.tensor(g["tvns"]).cuda()}
+    w = torch.randn(8, 61, 6, generator=torch.Generator().manual_seed(0)).cuda()
+    per = hode.capi.tape_nbytes(1, 60 + 32, 4, 4)
+
+    def grads(budget):
+        monkeypatch.setattr(HN, "TAPE_BUDGET_BYTES", budget)
+        m.zero_grad()
+        x0.grad = None
+        y = m(x0, t, ext)
+        (y * w).sum().backward()
+        return y.detach().clone(), x0.grad.clone(), torch.cat([p.grad.flatten() for p in m.nn_residual.parameters()])
+
+    y1, gx1, gn1 = grads(64 << 30)
+    y2, gx2, gn2 = grads(3 * per)                       # chunks of 3, 3, 2 patients
+    assert torch.equal(y1, y2) and torch.equal(gx1, gx2)
+    assert relnorm(gn2.cpu().numpy(), gn1.cpu().numpy()) < 2e-6
+
+    # VI: S = 3 parameter sets x 4 patients
+    prior = {f"ode_{n}": {"mean": v, "std": 0.1 * v} for n, v in
+             [("a_GI", 0.0104), ("k_I", 0.025), ("rho", 0.003), ("E_max", 0.1), ("EC_50", 50.0), ("V_max", 9.0), ("K_m", 7.0), ("k_L", 0.02)]}
+    torch.manual_seed(0)
+    v = M.HybridODENN(nn_hidden=16, nn_layers=2, use_variational=True, prior_params=prior, device="cuda")
+    with torch.no_grad():
+        for n, p in v.variational_params.means.items():
+            if n.startswith("nn_"):
+                p.normal_(0, 0.05)
+        for n, p in v.variational_params.log_stds.items():
+            p.fill_(-3.0 if n.startswith("nn_") else float(np.log(0.02 * prior[n]["mean"])))
+    batch = {"initial_state": x0.detach()[:4], "observations": torch.tensor(g["y_rk45_tight"][:4]).cuda(), "time_points": t,
+             "external_inputs": {k: u[:4] for k, u in ext.items()}}
+    per2 = hode.capi.tape_nbytes(1, 60 + 32, 4, 2)
+
+    def vi(budget):
+        monkeypatch.setattr(HN, "TAPE_BUDGET_BYTES", budget)
+        torch.manual_seed(5)
+        v.zero_grad()
+        e = v.elbo(batch, n_samples=3, noise_sigma=0.5)
+        e.backward()
+        vp = v.variational_params
+        return float(e), torch.cat([vp.means[n].grad.flatten() for n in vp.param_shapes] +
+                                   [vp.log_stds[n].grad.flatten() for n in vp.param_shapes]).cpu().numpy()
+    e0, g0 = vi(64 << 30)
+    for budget in (5 * per2, 9 * per2, 2 * per2):       # 1 set per chunk, 2 + 1 sets, 2 patients of one set per chunk
+        e1, g1 = vi(budget)
+        assert e1 == e0 and relnorm(g1, g0) < 2e-6, budget
