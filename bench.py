@@ -88,10 +88,28 @@ def cpu_baseline(sample, seconds_budget=20.0):
     with ThreadPoolExecutor(ncores) as ex:        # ctypes releases the GIL: real threads
         list(ex.map(work, chunks))
     dt = time.perf_counter() - t0
-    return {"value": sample / dt, "unit": "patient-trajectories/s", "cores": ncores, "kind": "port",
-            "sample": f"{sample} trajectories of the same synthetic cohort (T=241, fp32, rtol 1e-6/atol 1e-8), "
-                      f"C oracle, {ncores} threads, {dt:.1f} s wall",
-            "per_core": sample / dt / ncores}
+    out = {"value": sample / dt, "unit": "patient-trajectories/s", "cores": ncores, "kind": "port",
+           "sample": f"{sample} trajectories of the same synthetic cohort (T=241, fp32, rtol 1e-6/atol 1e-8), "
+                     f"C oracle, {ncores} threads, {dt:.1f} s wall",
+           "per_core": sample / dt / ncores}
+    out["parity_check"] = parity_check(O, x0[:16], t, meal[:16], tvns[:16], nn, ode)
+    return out
+
+
+def parity_check(O, x0, t, meal, tvns, nn, ode):
+    """The metric's second half ("adjoint grad rel-err"): 16 trajectories of the benchmark cohort, HIP fp32 at the benchmark
+    tolerances against the oracle in fp64 at 1e-10 / 1e-12 (checker only)."""
+    import hode
+    dev = torch.device("cuda", torch.cuda.current_device())
+    f32 = lambda a: torch.as_tensor(a, dtype=torch.float32, device=dev)          # noqa: E731
+    sol = hode.solve_fwd(f32(x0), f32(t), f32(meal), f32(tvns), None, f32(ode), f32(nn), H, L, want_tape=True)
+    ref = O.solve(x0, t, meal, tvns, None, ode, nn, H, L, rtol=1e-10, atol=1e-12, dtype=np.float64, want_tape=True)
+    c = np.random.default_rng(0).standard_normal(ref.y.shape)
+    _, gnn, _ = hode.solve_bwd(sol, f32(c))
+    _, rnn, _ = O.solve_bwd(ref, c)
+    return {"forward_rel_err": float(np.max(np.abs(sol.y.cpu().numpy() - ref.y) / (np.abs(ref.y) + 1e-3))),
+            "adjoint_grad_rel_err": float(np.linalg.norm(gnn.cpu().numpy() - rnn) / np.linalg.norm(rnn)),
+            "bars": {"forward": 1e-3, "adjoint": 1e-4}, "sample": "16 trajectories of the benchmark cohort, T=241"}
 
 
 def data_side(dev, B, cpu=True):
