@@ -151,6 +151,14 @@ def test_k8_windows_vs_reference_dataset(golden_dir, name, src, tmp_path):
     np.testing.assert_allclose(item["initial_state"].numpy(), g["initial_state"][-1], rtol=2e-7, atol=1e-7)
     raw = ds.sequences[0]
     assert raw["states"].shape == (int(g["seq_len"]), 6) and (raw["states"][:, 5] == 1).all()
+    if name == "4gi_20_10":                    # the other on-disk format the reference accepts (train_hybrid.py:66-67)
+        pq = str(tmp_path / "frame.parquet")
+        try:
+            pd.DataFrame(t["table"], columns=list(t["columns"])).to_parquet(pq)
+        except ImportError:                    # no parquet engine importable on this box: nothing to read back
+            return
+        ds2 = GlucoseDataset(pq, sequence_length=int(g["seq_len"]), stride=int(g["stride"]), normalize=bool(g["normalize"]))
+        assert torch.equal(ds2._states, ds._states) and np.array_equal(ds2.state_std, ds.state_std)
 
 
 def test_k8_vs_oracle_random_frames_and_edges():
