@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from _data_helpers import frame_from_table, reference_stream
+from _data_helpers import reference_stream
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"

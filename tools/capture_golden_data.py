@@ -10,7 +10,6 @@ module and run in a namespace holding numpy / pandas / torch.  Nothing is stubbe
 reference's outputs) is written to tests/golden/.
 """
 import ast
-import io
 import os
 import sys
 

@@ -6,7 +6,6 @@ import os
 import sys
 import time
 
-import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -34,7 +33,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=256)
     args = ap.parse_args()
     import hode
-    from hode.datagen import FourGIModel, GlucoseDataset, grid_points
+    from hode.datagen import grid_points
     dev = "cuda"
     B, T = args.subjects, grid_points(args.hours, 5)
     g = torch.Generator(device=dev).manual_seed(0)
