@@ -264,7 +264,7 @@ template <typename R, int NL, bool GODE, bool WTREG> static int launch_bwd_k(hip
     return a.gd_mode != 0 ? launch_bwd_g<R, NL, GODE, WTREG, true>(s, a, method) : launch_bwd_g<R, NL, GODE, WTREG, false>(s, a, method);
 }
 
-// fp32 default: transposed matrices in LDS, 2 waves/SIMD (measured 11.0 ms per 4096x241 adjoint).
+// fp32 default: transposed matrices in LDS, 2 waves/SIMD (measured 8.2 ms per 4096x241 adjoint).
 // HODE_BWD_WT=regs selects the register-resident variant (1 wave/SIMD, 13.9 ms) for comparison.
 static bool bwd_wt_in_regs()
 {
