@@ -248,7 +248,9 @@ template <typename R, int NL, bool GODE, bool WTREG, bool GD> static int launch_
     const int per_set = a.B / a.n_sets;
     int blocks = (per_set + kW - 1) / kW;
     if (blocks > 256) blocks = 256;             // one workgroup per CU, waves loop over trajectories
-    if (a.n_sets > 1 && blocks * a.n_sets > 256) blocks = (256 + a.n_sets - 1) / a.n_sets;
+    // never more workgroups than CUs when that is avoidable: 86 x 3 = 258 would leave two workgroups for a second round
+    // that doubles the kernel time
+    if (a.n_sets > 1 && blocks * a.n_sets > 256) blocks = 256 / a.n_sets;
     if (blocks < 1) blocks = 1;
     const size_t lds = bwd_lds_elems<R, NL>() * sizeof(R);
     dim3 grid(blocks, a.n_sets), block(64 * kW);

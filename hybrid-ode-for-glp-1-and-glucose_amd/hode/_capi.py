@@ -150,7 +150,7 @@ def solve_fwd(x0, t, meal, tvns, gd, ode_p, nn_p, H, L, method=METHOD_DP54, rtol
         # tape), so the default is tighter there; a trajectory that needs more reports status 1.
         if method == METHOD_RK4:
             max_steps = max(T - 1, 1)
-        elif want_tape:
+        elif want_tape or tape is not None:
             max_steps = (T - 1) + max(32, (T - 1) // 4)
         else:
             max_steps = 8 * (T - 1) + 64

@@ -52,10 +52,15 @@ def main():
         t0 = time.perf_counter()
         opt.zero_grad()
         e = m.elbo(batch, n_samples=a.samples, noise_sigma=0.1)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
         (-e).backward()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
         opt.step()
         torch.cuda.synchronize()
         times.append(time.perf_counter() - t0)
+        print(f"   elbo forward {t1 - t0:.3f} s, backward {t2 - t1:.3f} s, optimizer {time.perf_counter() - t2:.3f} s")
         vals.append(float(e))
         print(f"step {it}: {times[-1]:.3f} s  elbo {vals[-1]:.6g}  peak mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB", flush=True)
     ok = int((m.last_solve_info["status"] == 0).sum())
