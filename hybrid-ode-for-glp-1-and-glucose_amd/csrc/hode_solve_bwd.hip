@@ -125,7 +125,8 @@ __global__ __launch_bounds__(WTREG ? 256 : 64 * kBwdWaves, (sizeof(R) == 4 && !W
         }
     };
 
-    for (int bi = blockIdx.x * kWaves + wave; bi < per_set; bi += gridDim.x * kWaves) {
+    // wave-major distribution: a batch smaller than 8 x the grid keeps every CU busy with fewer active waves each
+    for (int bi = wave * gridDim.x + blockIdx.x; bi < per_set; bi += gridDim.x * kWaves) {
         const int b = set * per_set + bi;
         const R *__restrict__ tg = a.t + (a.t_batched ? (size_t)b * T : 0);
         const R *__restrict__ tape = a.tape + (size_t)b * a.max_steps * 8;
@@ -246,8 +247,7 @@ template <typename R, int NL, bool GODE, bool WTREG, bool GD> static int launch_
 {
     constexpr int kW = WTREG ? 4 : kBwdWaves;
     const int per_set = a.B / a.n_sets;
-    int blocks = (per_set + kW - 1) / kW;
-    if (blocks > 256) blocks = 256;             // one workgroup per CU, waves loop over trajectories
+    int blocks = per_set < 256 ? per_set : 256;   // one workgroup per CU, its waves loop over trajectories (wave-major)
     // never more workgroups than CUs when that is avoidable: 86 x 3 = 258 would leave two workgroups for a second round
     // that doubles the kernel time
     if (a.n_sets > 1 && blocks * a.n_sets > 256) blocks = 256 / a.n_sets;
