@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Time HybridODENN.loss(...).backward() (data + physics + regularisation, the reference's default training objective)."""
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "hybrid-ode-for-glp-1-and-glucose_amd"))
+import bench  # noqa: E402
+from models import HybridODENN  # noqa: E402
+
+dev = torch.device("cuda")
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+x0, t, meal, tvns = (v.to(dev) for v in bench.synth_cohort(B, 1000))
+torch.manual_seed(0)
+m = HybridODENN(device=dev)
+with torch.no_grad():
+    off, w = 0, bench.synth_weights(0)
+    for p in m.nn_residual.parameters():
+        p.copy_(w[off:off + p.numel()].reshape(p.shape)); off += p.numel()
+    obs = m(x0, t, {"meal": meal, "tVNS": tvns}) + 0.1 * torch.randn(B, bench.T, 6, device=dev)
+batch = {"initial_state": x0, "observations": obs, "time_points": t, "external_inputs": {"meal": meal, "tVNS": tvns}}
+for physics in (False, True):
+    for rep in range(3):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        m.zero_grad()
+        loss = m.loss(batch, 1.0, 1e-4, use_physics_loss=physics)
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        loss.backward()
+        torch.cuda.synchronize(); t2 = time.perf_counter()
+    print(f"B={B} physics={physics}: loss {1e3 * (t1 - t0):.1f} ms, backward {1e3 * (t2 - t1):.1f} ms, value {float(loss):.5f}")
