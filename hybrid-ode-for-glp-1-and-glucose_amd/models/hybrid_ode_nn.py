@@ -71,6 +71,13 @@ class _RhsFn(torch.autograd.Function):
 TAPE_BUDGET_BYTES = 64 << 30
 
 
+def _tape_budget(dev):
+    """min(TAPE_BUDGET_BYTES, 80 % of what the allocator can still hand out on this device) -- no synchronisation."""
+    free, _ = torch.cuda.mem_get_info(dev)
+    reusable = torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)     # cached blocks torch can re-use
+    return max(1, min(TAPE_BUDGET_BYTES, int(0.8 * (free + reusable))))
+
+
 def _tape_steps(T, method):
     return max(T - 1, 1) if method == hode.METHOD_RK4 else (T - 1) + max(32, (T - 1) // 4)
 
@@ -84,14 +91,15 @@ class _SolveFn(torch.autograd.Function):
         B, T = x0.shape[0], t.shape[-1]
         steps = _tape_steps(T, method)
         per_traj = hode.capi.tape_nbytes(1, steps, x0.element_size(), L)
-        ctx.chunked = need_tape and B * per_traj > TAPE_BUDGET_BYTES
+        budget = _tape_budget(x0.device) if need_tape else 0
+        ctx.chunked = need_tape and B * per_traj > budget
         # same accepted-step budget on both routes, so a chunked solve returns the same trajectories bit for bit
         sol = hode.solve_fwd(x0, t, meal, tvns, gd, ode_vec, nn_flat, H, L, method=method, rtol=rtol, atol=atol,
                              n_sets=n_sets, want_tape=need_tape and not ctx.chunked, max_steps=steps if need_tape else None)
         ctx.sol = sol if need_tape and not ctx.chunked else None
         if ctx.chunked:
             ctx.args = (x0, nn_flat, ode_vec, t, meal, tvns, gd, H, L, method, rtol, atol, n_sets, steps,
-                        max(1, TAPE_BUDGET_BYTES // per_traj))
+                        per_traj)
         info["status"], info["nsteps"], info["nfev"] = sol.status, sol.nsteps, sol.nfev
         return sol.y
 
@@ -103,8 +111,9 @@ class _SolveFn(torch.autograd.Function):
             gx0, gnn, gode = hode.solve_bwd(ctx.sol, gy.contiguous(), want_gnn=need[1], want_gode=need[2])
             ctx.sol = None
             return (gx0 if need[0] else None, gnn, gode) + (None,) * 11
-        x0, nn_flat, ode_vec, t, meal, tvns, gd, H, L, method, rtol, atol, n_sets, steps, cap = ctx.args
+        x0, nn_flat, ode_vec, t, meal, tvns, gd, H, L, method, rtol, atol, n_sets, steps, per_traj = ctx.args
         ctx.args = None
+        cap = max(1, _tape_budget(x0.device) // per_traj)      # what fits NOW (other tapes may have been freed or made)
         gy = gy.contiguous()
         B, P = x0.shape[0], nn_flat.numel() // n_sets
         G = B // n_sets                                   # trajectories per parameter set (contiguous groups)

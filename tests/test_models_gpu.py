@@ -448,3 +448,11 @@ def test_tape_budget_chunked_adjoint_equals_single_launch(M, golden_dir, monkeyp
     for budget in (5 * per2, 9 * per2, 2 * per2):       # 1 set per chunk, 2 + 1 sets, 2 patients of one set per chunk
         e1, g1 = vi(budget)
         assert e1 == e0 and relnorm(g1, g0) < 2e-6, budget
+    # the budget also bows to what the device can still allocate (80 % of free + re-usable cached memory)
+    monkeypatch.setattr(HN, "TAPE_BUDGET_BYTES", 64 << 30)
+    monkeypatch.setattr(torch.cuda, "mem_get_info", lambda dev=None: (3 * per, 288 << 30))
+    monkeypatch.setattr(torch.cuda, "memory_reserved", lambda dev=None: 0)
+    monkeypatch.setattr(torch.cuda, "memory_allocated", lambda dev=None: 0)
+    assert HN._tape_budget(torch.device("cuda")) == int(0.8 * 3 * per)
+    y3, gx3, gn3 = grads(64 << 30)                      # 2 patients per chunk now
+    assert torch.equal(y1, y3) and torch.equal(gx1, gx3) and relnorm(gn3.cpu().numpy(), gn1.cpu().numpy()) < 2e-6
