@@ -138,6 +138,23 @@ class _SolveFn(torch.autograd.Function):
         return (gx0 if need[0] else None, gnn, gode) + (None,) * 11
 
 
+def _allreduce_sum(tensors, group):
+    """One all-reduce(sum) of several device tensors (flattened into one fp64 buffer: 16 x 13 527 values for config 5).
+    RCCL for an "nccl" group; staged through the host for gloo (rehearsal on one GPU, CPU tests)."""
+    import torch.distributed as dist
+    flat = torch.cat([v.reshape(-1).double() for v in tensors])
+    if dist.get_backend(group) == "nccl":
+        dist.all_reduce(flat, group=group)
+    else:
+        host = flat.cpu()
+        dist.all_reduce(host, group=group)
+        flat = host.to(flat.device)
+    off = 0
+    for v in tensors:
+        v.copy_(flat[off:off + v.numel()].reshape(v.shape).to(v.dtype))
+        off += v.numel()
+
+
 def _pieces(n_sets, G, cap):
     """Split n_sets x G trajectories into pieces of at most `cap`: whole parameter sets when one fits, slices of a
     set otherwise.  -> [(first set, last set + 1, lo, hi)] with [lo, hi) the patient range inside a set; largest first."""
@@ -155,7 +172,7 @@ class _GaussLikFn(torch.autograd.Function):
     config 5: 0.58 -> 0.44 s per step), no S-fold copies of the inputs, and y itself lives only piece by piece."""
 
     @staticmethod
-    def forward(ctx, x0, nn_flat, ode_vec, t, meal, tvns, gd, obs, H, L, method, rtol, atol, S, info):
+    def forward(ctx, x0, nn_flat, ode_vec, t, meal, tvns, gd, obs, H, L, method, rtol, atol, S, info, group=None):
         need = ctx.needs_input_grad
         grads = any(need[:3])
         B, T = x0.shape[0], t.shape[-1]
@@ -185,6 +202,10 @@ class _GaussLikFn(torch.autograd.Function):
                     gode[17 * s0:17 * s1] += go
             stat.append(sol.status), nst.append(sol.nsteps), nfe.append(sol.nfev)
         info["status"], info["nsteps"], info["nfev"] = torch.cat(stat), torch.cat(nst), torch.cat(nfe)
+        if group is not None:
+            # patients sharded over the ranks, the SAME S draws everywhere: one all-reduce(sum) of
+            # [per-set MLP grads | per-set ODE grads | sum of squares] makes value and gradient global on every rank
+            _allreduce_sum([v for v in (gnn, gode, ss) if v is not None], None if group is True else group)
         ctx.grads = (gx0, gnn, gode)
         return ss[0]
 
@@ -194,7 +215,7 @@ class _GaussLikFn(torch.autograd.Function):
         gx0, gnn, gode = ctx.grads
         ctx.grads = None
         sc = lambda v: None if v is None else (v * g.to(v.dtype))          # noqa: E731
-        return (sc(gx0), sc(gnn), sc(gode)) + (None,) * 12
+        return (sc(gx0), sc(gnn), sc(gode)) + (None,) * 13
 
 
 class HybridODENN(nn.Module):
@@ -416,14 +437,18 @@ class HybridODENN(nn.Module):
 
     # ------------------------------------------------------------------ ELBO (BASELINE config 5)
     def elbo(self, batch: Dict[str, torch.Tensor], n_samples: int = 16, noise_sigma: float = 0.1,
-             solver: str = "dopri5", rtol: float = 1e-6, atol: float = 1e-8) -> torch.Tensor:
+             solver: str = "dopri5", rtol: float = 1e-6, atol: float = 1e-8, group=None) -> torch.Tensor:
         """Monte-Carlo ELBO of reference inference/vi.py:60-118 (`VariationalInference.elbo`):
              E_q[log p(obs | theta)] - KL[q || p],   theta_s = mu + eps_s * exp(log_sigma),  s = 1..S,
         one parameter draw shared by the whole batch per sample (vi.py:88-100).  All S x B trajectories are
         ONE launch (the S draws ride in the kernel's parameter-set dimension) and -- unlike the reference,
         whose likelihood term is detached -- the reparameterised gradient reaches mu / log_sigma
         through the adjoint kernel (per-set MLP and ODE-constant gradients).  KL and the likelihood sum are
-        accumulated in fp64."""
+        accumulated in fp64.
+        group: one process per GPU, `batch` = this rank's shard of the patients, torch's RNG seeded identically on
+        every rank (same draws): the data term and its gradient are summed over the group with ONE all-reduce, the KL
+        term is parameter-only and computed redundantly -- every rank returns the ELBO of the whole cohort and ends the
+        backward with identical gradients."""
         if not self.use_variational:
             raise ValueError("Model was not initialized with variational inference")
         self._check_supported()
@@ -437,18 +462,24 @@ class HybridODENN(nn.Module):
         ode_vec = torch.cat([f[1] for f in flat])
 
         n_obs = obs.numel()
+        if group is not None:
+            if not (self.fused_likelihood and self.adjoint):
+                raise ValueError("elbo(group=...) needs the fused likelihood route (fused_likelihood and adjoint both True)")
+            cnt = torch.tensor([float(n_obs)], dtype=torch.float64, device=dev)
+            _allreduce_sum([cnt], None if group is True else group)
+            n_obs = float(cnt)
         log_norm = 0.5 * n_obs * torch.log(torch.tensor(2 * torch.pi * noise_sigma ** 2, dtype=torch.float64, device=dev))
         kl = self.variational_params.kl_divergence().double().to(dev)
         method = _SOLVERS.get(str(solver).lower())
         if method is None:
             raise ValueError(f"unknown solver {solver!r}; known: {sorted(_SOLVERS)}")
-        if self.fused_likelihood and self.adjoint and torch.is_grad_enabled():
+        if self.fused_likelihood and self.adjoint and (torch.is_grad_enabled() or group is not None):
             # data term and its gradient in one pass over the S x B trajectories (_GaussLikFn)
             xs, tt, ins = self._prep_inputs(x0, tp, u, dev)
             info, nl = {}, self.nn_residual
             ss = _GaussLikFn.apply(xs, nn_flat, ode_vec, tt, ins["meal"], ins["tVNS"], ins["GD"],
                                    obs.to(dev, torch.float32).contiguous(), nl.hidden_dim, nl.n_layers, method, float(rtol),
-                                   float(atol), S, info)
+                                   float(atol), S, info, group)
             self.last_solve_info = info
             self._warn_failures(info)
             return (-0.5 * ss / (noise_sigma ** 2 * S) - log_norm - kl).to(self.device)

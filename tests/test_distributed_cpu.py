@@ -118,3 +118,35 @@ def test_pack_unpack_and_shards():
         b = [T.shard_bounds(n, r, w) for r in range(w)]
         assert b[0][0] == 0 and b[-1][1] == n and all(b[i][1] == b[i + 1][0] for i in range(w - 1))
         assert max(h - l for l, h in b) - min(h - l for l, h in b) <= 1
+
+
+def _allreduce_worker(rank, world, port, q):
+    from models.hybrid_ode_nn import _allreduce_sum
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    gnn = torch.arange(6, dtype=torch.float32).reshape(2, 3) * (rank + 1)
+    gode = torch.ones(17, dtype=torch.float32) * (rank + 1)
+    ss = torch.tensor([1.0 + 2.0 ** -40 * (rank + 1)], dtype=torch.float64)          # needs fp64 to survive the sum
+    _allreduce_sum([gnn, gode, ss], None)
+    q.put((rank, gnn.numpy().copy(), gode.numpy().copy(), ss.numpy().copy(), str(gnn.dtype), str(ss.dtype)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_elbo_gradient_allreduce_helper():
+    """The ONE collective of a sharded ELBO step (models/hybrid_ode_nn.py:_allreduce_sum): several tensors, one fp64
+    buffer, dtypes and shapes restored, identical result on every rank."""
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_allreduce_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for _, gnn, gode, ss, d1, d2 in res:
+        assert np.array_equal(gnn, np.arange(6, dtype=np.float32).reshape(2, 3) * 6) and (gode == 6).all()
+        assert ss[0] == 3.0 + 2.0 ** -40 * 6 and d1 == "torch.float32" and d2 == "torch.float64"

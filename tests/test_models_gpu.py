@@ -463,3 +463,74 @@ def test_tape_budget_chunked_adjoint_equals_single_launch(M, golden_dir, monkeyp
     assert HN._tape_budget(torch.device("cuda")) == int(0.8 * 3 * per)
     y3, gx3, gn3 = grads(64 << 30)                      # 2 patients per chunk now
     assert torch.equal(y1, y3) and torch.equal(gx1, gx3) and relnorm(gn3.cpu().numpy(), gn1.cpu().numpy()) < 2e-6
+
+
+def _vi_model(M):
+    prior = {f"ode_{n}": {"mean": v, "std": 0.1 * v} for n, v in
+             [("a_GI", 0.0104), ("k_I", 0.025), ("rho", 0.003), ("E_max", 0.1), ("EC_50", 50.0), ("V_max", 9.0), ("K_m", 7.0), ("k_L", 0.02)]}
+    torch.manual_seed(0)
+    v = M.HybridODENN(nn_hidden=16, nn_layers=2, use_variational=True, prior_params=prior, device="cuda")
+    with torch.no_grad():
+        for n, p in v.variational_params.means.items():
+            if n.startswith("nn_"):
+                p.normal_(0, 0.05)
+        for n, p in v.variational_params.log_stds.items():
+            p.fill_(-3.0 if n.startswith("nn_") else float(np.log(0.02 * prior[n]["mean"])))
+    return v
+
+
+def _vi_batch(golden_dir, lo, hi):
+    g = np.load(os.path.join(golden_dir, "g4_t61_pulses.npz"))
+    c = lambda a: torch.tensor(a[lo:hi]).cuda()                       # noqa: E731
+    return {"initial_state": c(g["x0"]), "observations": c(g["y_rk45_tight"]), "time_points": torch.tensor(g["t"]).cuda(),
+            "external_inputs": {"meal": c(g["meal"]), "tVNS": c(g["tvns"])}}
+
+
+def _vi_grads(v):
+    vp = v.variational_params
+    return torch.cat([vp.means[n].grad.flatten() for n in vp.param_shapes] + [vp.log_stds[n].grad.flatten() for n in vp.param_shapes])
+
+
+def _elbo_rank(rank, world, port, golden_dir, q):
+    import torch.distributed as dist
+    import models as M
+    from hode.train import shard_bounds
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)      # rehearsal backend: the ranks share cuda:0
+    v = _vi_model(M)
+    lo, hi = shard_bounds(8, rank, world)
+    torch.manual_seed(5)                                               # the same draws on every rank
+    e = v.elbo(_vi_batch(golden_dir, lo, hi), n_samples=3, noise_sigma=0.5, group=True)
+    e.backward()
+    q.put((rank, float(e), _vi_grads(v).cpu().numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_elbo_sharded_over_two_ranks_equals_single_process(M, golden_dir):
+    """BASELINE config 5's multi-GPU shape: patients sharded, identical draws, ONE all-reduce of the data term and its
+    gradient, KL redundant.  Every rank must return the single-process ELBO and gradients."""
+    import socket
+    import torch.multiprocessing as mp
+    v = _vi_model(M)
+    torch.manual_seed(5)
+    e = v.elbo(_vi_batch(golden_dir, 0, 8), n_samples=3, noise_sigma=0.5)
+    e.backward()
+    e0, g0 = float(e), _vi_grads(v).cpu().numpy()
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_elbo_rank, args=(r, 2, port, golden_dir, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda r: r[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for _, e1, g1 in res:
+        assert abs(e1 - e0) <= 1e-9 * abs(e0)
+        assert relnorm(g1, g0) < 2e-6
+    assert res[0][1] == res[1][1] and np.array_equal(res[0][2], res[1][2])      # replicas stay bit-identical
