@@ -172,7 +172,8 @@ class _GaussLikFn(torch.autograd.Function):
     config 5: 0.58 -> 0.44 s per step), no S-fold copies of the inputs, and y itself lives only piece by piece."""
 
     @staticmethod
-    def forward(ctx, x0, nn_flat, ode_vec, t, meal, tvns, gd, obs, H, L, method, rtol, atol, S, info, group=None):
+    def forward(ctx, x0, nn_flat, ode_vec, t, meal, tvns, gd, obs, H, L, method, rtol, atol, S, info, group=None,
+                want_y=False):
         need = ctx.needs_input_grad
         grads = any(need[:3])
         B, T = x0.shape[0], t.shape[-1]
@@ -183,7 +184,7 @@ class _GaussLikFn(torch.autograd.Function):
         gx0 = torch.zeros_like(x0) if need[0] else None
         gnn = torch.zeros_like(nn_flat) if need[1] else None
         gode = torch.zeros_like(ode_vec) if need[2] else None
-        tape, stat, nst, nfe = None, [], [], []
+        tape, stat, nst, nfe, ys = None, [], [], [], []
         for s0, s1, lo, hi in _pieces(S, B, cap):
             m = s1 - s0
             rep = lambda v: None if v is None else (v[lo:hi].repeat(m, *([1] * (v.dim() - 1))) if m > 1 else v[lo:hi])  # noqa: E731
@@ -201,21 +202,27 @@ class _GaussLikFn(torch.autograd.Function):
                 if go is not None:
                     gode[17 * s0:17 * s1] += go
             stat.append(sol.status), nst.append(sol.nsteps), nfe.append(sol.nfev)
+            if want_y:
+                ys.append(sol.y)
         info["status"], info["nsteps"], info["nfev"] = torch.cat(stat), torch.cat(nst), torch.cat(nfe)
         if group is not None:
             # patients sharded over the ranks, the SAME S draws everywhere: one all-reduce(sum) of
             # [per-set MLP grads | per-set ODE grads | sum of squares] makes value and gradient global on every rank
             _allreduce_sum([v for v in (gnn, gode, ss) if v is not None], None if group is True else group)
         ctx.grads = (gx0, gnn, gode)
+        if want_y:                                     # the trajectories themselves (S = 1), e.g. for the physics points
+            y = ys[0] if len(ys) == 1 else torch.cat(ys)
+            ctx.mark_non_differentiable(y)
+            return ss[0], y
         return ss[0]
 
     @staticmethod
     @torch.autograd.function.once_differentiable
-    def backward(ctx, g):
+    def backward(ctx, g, *_):
         gx0, gnn, gode = ctx.grads
         ctx.grads = None
         sc = lambda v: None if v is None else (v * g.to(v.dtype))          # noqa: E731
-        return (sc(gx0), sc(gnn), sc(gode)) + (None,) * 13
+        return (sc(gx0), sc(gnn), sc(gode)) + (None,) * 14
 
 
 class HybridODENN(nn.Module):
@@ -234,7 +241,8 @@ class HybridODENN(nn.Module):
         # True  (default): gradients flow through the solve by the adjoint kernel (north_star).
         # False: the solve is detached exactly like the reference's SciPy round trip.
         self.adjoint = True
-        # elbo(): compute the Gaussian data term and its gradient in one pass (no tape kept for a later backward)
+        # elbo() / loss(): compute the Gaussian (MSE) data term and its gradient in one pass over the batch -- no tape
+        # kept for a later backward.  False: the solve goes through autograd like any other op (_SolveFn).
         self.fused_likelihood = True
         self.last_solve_info: Dict[str, torch.Tensor] = {}
         self.variational_params = None
@@ -513,9 +521,23 @@ class HybridODENN(nn.Module):
         u = batch.get("external_inputs", None)
         dev = _compute_device()
 
-        pred = self._solve(x0, tp, u, "dopri5", 1e-6, 1e-8)          # defaults, like reference :291
-        self._warn_failures(self.last_solve_info)
-        data_loss = torch.nn.functional.mse_loss(pred, obs.to(dev, torch.float32))
+        if self.fused_likelihood and self.adjoint and torch.is_grad_enabled():
+            # solve + MSE + adjoint piece by piece in one pass (_GaussLikFn): no tape is held until backward() and a
+            # cohort whose tape exceeds the budget needs no second forward.  Defaults like reference :291.
+            self._check_supported()
+            xs, tt, ins = self._prep_inputs(x0, tp, u, dev)
+            nn_flat, ode_vec = self._params_on(dev)
+            info, nl = {}, self.nn_residual
+            ss, pred = _GaussLikFn.apply(xs, nn_flat, ode_vec, tt, ins["meal"], ins["tVNS"], ins["GD"],
+                                         obs.to(dev, torch.float32).contiguous(), nl.hidden_dim, nl.n_layers, hode.METHOD_DP54,
+                                         1e-6, 1e-8, 1, info, None, True)
+            self.last_solve_info = info
+            self._warn_failures(info)
+            data_loss = (ss / obs.numel()).float()
+        else:
+            pred = self._solve(x0, tp, u, "dopri5", 1e-6, 1e-8)      # defaults, like reference :291
+            self._warn_failures(self.last_solve_info)
+            data_loss = torch.nn.functional.mse_loss(pred, obs.to(dev, torch.float32))
 
         physics_loss = torch.zeros((), device=dev)
         if use_physics_loss and lambda1 > 0:

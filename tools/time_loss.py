@@ -23,12 +23,13 @@ with torch.no_grad():
         p.copy_(w[off:off + p.numel()].reshape(p.shape)); off += p.numel()
     obs = m(x0, t, {"meal": meal, "tVNS": tvns}) + 0.1 * torch.randn(B, bench.T, 6, device=dev)
 batch = {"initial_state": x0, "observations": obs, "time_points": t, "external_inputs": {"meal": meal, "tVNS": tvns}}
-for physics in (False, True):
-    for rep in range(3):
+for physics, fused in ((False, True), (False, False), (True, True), (True, False), (False, True), (False, False)):
+    m.fused_likelihood = fused
+    for rep in range(4):
         torch.cuda.synchronize(); t0 = time.perf_counter()
         m.zero_grad()
         loss = m.loss(batch, 1.0, 1e-4, use_physics_loss=physics)
         torch.cuda.synchronize(); t1 = time.perf_counter()
         loss.backward()
         torch.cuda.synchronize(); t2 = time.perf_counter()
-    print(f"B={B} physics={physics}: loss {1e3 * (t1 - t0):.1f} ms, backward {1e3 * (t2 - t1):.1f} ms, value {float(loss):.5f}")
+    print(f"B={B} physics={physics} fused={fused}: loss {1e3 * (t1 - t0):.1f} ms, backward {1e3 * (t2 - t1):.1f} ms, value {float(loss):.5f}")
