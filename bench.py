@@ -13,6 +13,9 @@ collective in the forward path.  After the headline region the same shard is pus
 TRAINING step of config[2]/[3] (forward with tape -> fused MSE -> adjoint -> one RCCL all-reduce
 of the 54 KB gradient buffer -> fused clip+Adam) and reported under "train_step".
 
+At N = 1 two more legs follow: "vi_step" (BASELINE config 5 at its per-GPU size: 8 192 patients x 16 VI draws, ELBO +
+reparameterised gradient + Adam) and "data_side" (65 536-subject 4GI cohort generation + dataset windows).
+
 Rank 0 prints ONE JSON line.  `roofline` prices the solve kernel against the fp32 compute peak
 (the binding roof: ~5 000 flop/byte, SURVEY.md 8d) and also carries the HBM reading;
 `cpu_baseline` times the oracle (C port of the same algorithm) on the host cores, N = 1 only.
@@ -112,6 +115,44 @@ def parity_check(O, x0, t, meal, tvns, nn, ode):
             "bars": {"forward": 1e-3, "adjoint": 1e-4}, "sample": "16 trajectories of the benchmark cohort, T=241"}
 
 
+def vi_step(dev, patients, samples=16):
+    """BASELINE config 5 at its per-GPU size: one ELBO evaluation (S Monte-Carlo parameter draws x patients, KL and
+    likelihood in fp64) + reparameterised gradient through the adjoint + Adam on the variational parameters."""
+    from models import HybridODENN
+    x0, t, meal, tvns = (v.to(dev) for v in synth_cohort(patients, 777))
+    prior = {f"ode_{n}": {"mean": v, "std": 0.02 * v} for n, v in
+             [("a_GI", 0.0104), ("k_I", 0.025), ("rho", 0.003), ("E_max", 0.1), ("EC_50", 50.0), ("V_max", 9.0), ("K_m", 7.0), ("k_L", 0.02)]}
+    torch.manual_seed(0)
+    m = HybridODENN(use_variational=True, prior_params=prior, device=dev)
+    teacher = synth_weights(0)
+    with torch.no_grad():
+        off = 0
+        for name, p in m.nn_residual.named_parameters():
+            m.variational_params.means["nn_" + name.replace(".", "_")].copy_(teacher[off:off + p.numel()].reshape(p.shape))
+            off += p.numel()
+        for n, p in m.variational_params.log_stds.items():
+            p.fill_(-6.0 if n.startswith("nn_") else float(np.log(0.02 * prior[n]["mean"])))
+        obs = m.forward_with_params({k: v.detach() for k, v in m.variational_params.means.items()}, x0, t, {"meal": meal, "tVNS": tvns})
+    batch = {"initial_state": x0, "observations": obs + 0.1 * torch.randn_like(obs), "time_points": t,
+             "external_inputs": {"meal": meal, "tVNS": tvns}}
+    opt = torch.optim.Adam(m.variational_params.parameters(), lr=1e-3)
+    times = []
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        opt.zero_grad()
+        e = m.elbo(batch, n_samples=samples, noise_sigma=0.1)
+        (-e).backward()
+        opt.step()
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+    n = patients * samples
+    return {"workload": f"{patients} patients x {samples} VI draws (BASELINE config 5 per GPU), T={T}, fp32 solve, fp64 KL / likelihood",
+            "value": n / min(times[1:]), "unit": "patient-trajectories/s", "s_per_step": min(times[1:]), "trajectories": n,
+            "trajectories_ok": int((m.last_solve_info["status"] == 0).sum()), "elbo": float(e),
+            "peak_mem_gib": torch.cuda.max_memory_allocated(dev) / 2 ** 30}
+
+
 def data_side(dev, B, cpu=True):
     """SURVEY 8f-3 leg: generate a B-subject 4GI cohort (5 h at 5 min, 2 meals, 10 % noise: the reference's
     data/generate4GI.py __main__ configuration) on the device, then cut and z-score the windows (31 / 15)."""
@@ -169,6 +210,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true")
     ap.add_argument("--no-data-side", action="store_true")
+    ap.add_argument("--no-vi", action="store_true")
+    ap.add_argument("--vi-patients", type=int, default=8192, help="patients of the VI leg (BASELINE config 5: 8 192 per GPU x 16 draws)")
     ap.add_argument("--cohort", type=int, default=65536, help="subjects of the data-side leg (4GI generator + windows)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, default) | gloo (rehearsal: ranks may share one GPU)")
     args = ap.parse_args()
@@ -320,6 +363,8 @@ def main():
             out["zscore_regime"] = zs
         if train is not None:
             out["train_step"] = train
+        if world == 1 and not args.no_vi:
+            out["vi_step"] = vi_step(dev, args.vi_patients)
         if world == 1 and not args.no_data_side:
             out["data_side"] = data_side(dev, args.cohort, cpu=not args.no_cpu_baseline)
         if world == 1 and not args.no_cpu_baseline:

@@ -8,7 +8,7 @@ OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-ARGS="--steps 5 --warmup 2 --train-steps 2 --no-cpu-baseline"
+ARGS="--steps 5 --warmup 2 --train-steps 2 --no-cpu-baseline --no-vi"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py $ARGS > $OUT/bench_trace.log 2>&1
 echo "trace done"
 for C in FETCH_SIZE WRITE_SIZE "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU" "SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM SQ_INSTS_SMEM GRBM_GUI_ACTIVE"; do
