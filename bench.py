@@ -236,6 +236,13 @@ def main():
         else:
             dist.init_process_group("gloo")                     # rehearsal only (collectives staged through the host)
 
+    if not os.path.exists(os.path.join(ROOT, "hybrid-ode-for-glp-1-and-glucose_amd", "hode", "libhode.so")):
+        # fresh checkout (built artefacts are git-ignored): rank 0 of the node builds, the others wait
+        if local_rank == 0:
+            import __graft_entry__
+            __graft_entry__.build()
+        if world > 1:
+            dist.barrier()
     import hode
     hode.load()
     B = args.patients_per_gpu
