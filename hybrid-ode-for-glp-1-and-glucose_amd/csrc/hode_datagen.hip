@@ -31,6 +31,7 @@ __device__ __forceinline__ double powr_(double x, double p) { return p == 0.0 ? 
 // per-subject constants of generate4GI.py:94-116 (they depend on the subject's baselines only)
 struct Subject {
     double Bglc, S0glg, KINglc, KINins, KINglp, KINglg, KINgip;
+    double inv_1pS0glg;   // 1 / (1 + S0glg): a per-subject constant divisor of the RHS, applied as a multiplication
 };
 
 __device__ inline Subject subject_init(const FourGIPar &p, const double *bsl)
@@ -47,6 +48,7 @@ __device__ inline Subject subject_init(const FourGIPar &p, const double *bsl)
     s.KINglp = p.VM_GLP * Bglp * p.VCglp / (p.KM_GLP + Bglp);
     s.KINglg = Bglg * p.CLglg;
     s.KINgip = Bgip * p.CLgip;
+    s.inv_1pS0glg = 1.0 / (1.0 + s.S0glg);
     return s;
 }
 
@@ -54,20 +56,24 @@ __device__ inline Subject subject_init(const FourGIPar &p, const double *bsl)
 __device__ __forceinline__ void fourgi_rhs(const FourGIPar &p, const Subject &s, int hv, const double *y, double meal,
                                            double *d)
 {
-    const double Cglc = y[0] / p.VCglc, Cins = y[1] / p.VCins, Cglp = y[2] / p.VCglp, Cglg = y[3] / p.VCglg;
-    const double r = powr_(Cglp / p.EC50_1, p.HILL_1);
+    // Divisions by model constants are multiplications by reciprocals (wave-uniform, hoisted out of the stepping loop):
+    // an fp64 division is ~14 instructions, and 7 of the 12 per evaluation have a constant divisor.  <= 1 ulp per
+    // operation away from the reference's expression; the table's concentrations (emit_row) keep the true division.
+    const double iVCglc = 1.0 / p.VCglc, iVCins = 1.0 / p.VCins, iVCglp = 1.0 / p.VCglp, iVCglg = 1.0 / p.VCglg;
+    const double Cglc = y[0] * iVCglc, Cins = y[1] * iVCins, Cglp = y[2] * iVCglp, Cglg = y[3] * iVCglg;
+    const double r = powr_(Cglp * (1.0 / p.EC50_1), p.HILL_1);
     const double Sins = p.EMAX_1 * r / (1.0 + r);
-    const double q = Cglg / p.EC50_4;
+    const double q = Cglg * (1.0 / p.EC50_4);
     const double Sglg = p.EMAX_4 * q / (1.0 + q);
-    const double glg_on_glc = (1.0 + Sglg) / (1.0 + s.S0glg);
+    const double glg_on_glc = (1.0 + Sglg) * s.inv_1pS0glg;
     const double p2 = Cglc >= s.Bglc ? 0.925 : (hv ? 0.327 : 0.0);
     const double glc_on_glg = Cglc > 0.0 ? powr_(s.Bglc / Cglc, p2) : 1.0;
     const double me = meal * 10.0;
     const bool fed = me > 0.0;
     const double fglp = fed ? p.FDGLP * me : 0.0, fgip = fed ? p.FDGIP * me : 0.0, fglg = fed ? p.FDGLG * me : 0.0;
-    const double k27 = p.Qglc / p.VCglc, k72 = p.Qglc / p.VPglc, k612 = p.Qgip / p.VCgip, k126 = p.Qgip / p.VPgip;
-    d[0] = meal + s.KINglc * glg_on_glc - k27 * y[0] + k72 * y[5] - (p.CLglc / p.VCglc) * y[0] -
-           (p.CLglci * y[6] / p.VCglc) * y[0];
+    const double k27 = p.Qglc * iVCglc, k72 = p.Qglc / p.VPglc, k612 = p.Qgip / p.VCgip, k126 = p.Qgip / p.VPgip;
+    d[0] = meal + s.KINglc * glg_on_glc - k27 * y[0] + k72 * y[5] - (p.CLglc * iVCglc) * y[0] -
+           (p.CLglci * y[6] * iVCglc) * y[0];
     d[1] = s.KINins * (1.0 + Sins * powr_(Cglc, p.GLCINS_S)) - (p.CLins / p.VCins) * y[1];
     d[2] = s.KINglp * (1.0 + fglp) - p.VM_GLP * Cglp / (p.KM_GLP + Cglp);
     d[3] = s.KINglg * (1.0 + fglg) * glc_on_glg - (p.CLglg / p.VCglg) * y[3];
