@@ -1,15 +1,16 @@
 /*
  * solve_from_c.c -- the C ABI of libhode.so used from plain C: no Python, no torch.
  *
- * Integrates a small cohort (B patients, T grid points, 5-minute grid) with the 4x64 MLP residual set to zero weights
- * except a small output bias (so the network path is exercised), once with DP5(4) in fp32 and once in fp64, and prints
- * the final states.  tests/test_c_example_gpu.py builds it, runs it on the GPU box and checks the printed numbers against
- * the oracle.
+ * Integrates a small cohort (B patients, T grid points, 5-minute grid) with a fully populated 4x64 MLP residual (every
+ * weight and bias drawn from a 32-bit LCG that tests/test_c_example.py reproduces, so all hidden layers multiply non-zero
+ * numbers), once with DP5(4) in fp32 and once in fp64, and prints the final states.  tests/test_c_example.py builds it, runs it
+ * on the GPU box and checks the printed numbers against the oracle.
  *
  * Build:  hipcc -x c -I include examples/solve_from_c.c -L hybrid-ode-for-glp-1-and-glucose_amd/hode -lhode \
  *               -Wl,-rpath,$PWD/hybrid-ode-for-glp-1-and-glucose_amd/hode -o examples/solve_from_c
  */
 #include <hip/hip_runtime_api.h>
+#include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -34,7 +35,16 @@ int main(void)
     /* ODECore constants in registration order (models/ode_core.py:44-71) */
     const double ode[17] = {0.0104, 0.025, 0.003, 5.0, 60.0, 0.1, 50.0, 80.0, 9.0, 7.0, 0.02, 0.01, 1000.0, 2.0, 0.05, 0.001, 0.01};
     double *nn = calloc((size_t)P, sizeof(double));
-    for (int o = 0; o < 6; ++o) nn[P - 6 + o] = 0.01 * (o - 2);                /* output bias only */
+    /* flat layout = PyTorch parameters() order: W1[H,9] b1[H] (W[H,H] b[H]) x (L-1) Wout[6,H] bout[6].  Numerical-Recipes LCG,
+     * u = top 24 bits / 2^24 - 0.5; hidden tensors +-0.15, the output layer +-0.01 (a residual of the size training produces) */
+    {
+        uint32_t s = 12345u;
+        const int n_out = 6 * H + 6;
+        for (int i = 0; i < P; ++i) {
+            s = s * 1664525u + 1013904223u;
+            nn[i] = ((double)(s >> 8) / 16777216.0 - 0.5) * (i >= P - n_out ? 0.02 : 0.3);
+        }
+    }
     double x0[B * 6], t[T], meal[B * T];
     const double base[6] = {5.0, 60.0, 80.0, 10.0, 0.0, 1.0};
     for (int b = 0; b < B; ++b)
@@ -79,7 +89,7 @@ int main(void)
             printf("\n");
         }
         /* an invalid call is refused before any launch */
-        if (pass == 0 && hode_solve_fwd_f32(stream, B, T, dx, dt, 0, dm, 2, NULL, 0, NULL, 0, dode, dnn, 1, 128, L, HODE_METHOD_DP54,
+        if (pass == 0 && hode_solve_fwd_f32(stream, B, T, dx, dt, 0, dm, 2, NULL, 0, NULL, 0, dode, dnn, 1, 1024, L, HODE_METHOD_DP54,
                                             1e-6, 1e-8, 4000, dy, dst, NULL, NULL, NULL) != HODE_EUNSUPPORTED) return 4;
         hipFree(dx); hipFree(dt); hipFree(dm); hipFree(dode); hipFree(dnn); hipFree(dy); hipFree(dst);
         free(hx); free(ht); free(hm); free(ho); free(hn); free(hy);

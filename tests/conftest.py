@@ -21,6 +21,24 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with gpurun)")
 
 
+# GPU suite order (the driver runs `pytest -x -m gpu`): the hot path first -- one test per BASELINE.json config
+# (test_cfg1..5), then the kernel parity file, the class surface, the plain-C program -- and the "next" rows (data side)
+# last, so a failure in a widening row can never hide the evidence for SURVEY section 8's (a) rows.
+_FILE_ORDER = ["test_hip_parity.py", "test_models_gpu.py", "test_vi_gpu.py", "test_c_example.py", "test_bench_contract_gpu.py",
+               "test_data_side_gpu.py"]
+
+
+def pytest_collection_modifyitems(config, items):
+    def key(pair):
+        i, item = pair
+        fname = os.path.basename(str(item.fspath))
+        name = item.name
+        if name.startswith("test_cfg") and name[8:9].isdigit():
+            return (0, int(name[8]), i)
+        return (1 + (_FILE_ORDER.index(fname) if fname in _FILE_ORDER else len(_FILE_ORDER)), 0, i)
+    items[:] = [it for _, it in sorted(enumerate(items), key=key)]
+
+
 def pytest_sessionstart(session):
     """A fresh checkout has no built artefacts (they are git-ignored): build libhode.so (hipcc cross-compiles for gfx950
     without a GPU) and the oracle once, exactly as __graft_entry__.build() does.  A failing build is reported by the

@@ -49,8 +49,10 @@ def test_c_program_matches_the_oracle(tmp_path):
     P = O.n_params(H, L)
     ode = np.array([0.0104, 0.025, 0.003, 5.0, 60.0, 0.1, 50.0, 80.0, 9.0, 7.0, 0.02, 0.01, 1000.0, 2.0, 0.05, 0.001, 0.01],
                    np.float32).astype(np.float64)
-    nn = np.zeros(P)
-    nn[P - 6:] = 0.01 * (np.arange(6) - 2)
+    nn, s = np.zeros(P), 12345                     # the C program's LCG: every layer populated
+    for i in range(P):
+        s = (s * 1664525 + 1013904223) & 0xFFFFFFFF
+        nn[i] = ((s >> 8) / 16777216.0 - 0.5) * (0.02 if i >= P - (6 * H + 6) else 0.3)
     nn = nn.astype(np.float32).astype(np.float64)
     x0 = np.array([5.0, 60.0, 80.0, 10.0, 0.0, 1.0])[None, :] * (1.0 + 0.02 * np.arange(B))[:, None]
     t = np.arange(T) * (5.0 / 60.0)
@@ -58,6 +60,9 @@ def test_c_program_matches_the_oracle(tmp_path):
     meal[np.arange(B), 3 + np.arange(B)] = 1.0
     ref = O.solve(x0, t, meal, None, None, ode, nn, H, L, rtol=1e-10, atol=1e-12, dtype=np.float64)
     assert (ref.status == 0).all()
+    # the MLP matters in this cohort: without it the end states differ by far more than the parity bar
+    bare = O.solve(x0, t, meal, None, None, ode, np.zeros(P), H, L, rtol=1e-10, atol=1e-12, dtype=np.float64)
+    assert np.max(np.abs(bare.y[:, -1] - ref.y[:, -1]) / (np.abs(ref.y[:, -1]) + 1e-3)) > 1e-2
     for b in range(B):
         want = ref.y[b, -1]
         assert np.max(np.abs(rows["f64"][b] - want) / (np.abs(want) + 1e-3)) < 1e-7

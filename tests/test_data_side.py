@@ -83,6 +83,47 @@ def test_oracle_windows_edge_cases():
     assert (w["states"][..., 4:] == 0).all()
 
 
+def test_read_frame_csv_vs_parquet(golden_dir, tmp_path):
+    """Host half of GlucoseDataset's loader on both on-disk formats the reference accepts (train_hybrid.py:64-67).
+    parquet round-trips the frame exactly; pandas' default CSV float parser does not (1 ulp on some values), which is
+    why the GPU test compares the two datasets at 1e-12 instead of bitwise."""
+    pd = pytest.importorskip("pandas")
+    from hode.datagen import GlucoseDataset
+    t = _g(golden_dir, "g9_4gi_dataset_table.npz")
+    cols = list(t["columns"])
+    df = pd.DataFrame(t["table"], columns=cols)
+    csv = str(tmp_path / "frame.csv")
+    df.to_csv(csv, index=False, float_format="%.17g")
+    tab_c, names_c, sid_c = GlucoseDataset.read_frame(csv)
+    assert names_c == cols and tab_c.dtype == np.float64 and tab_c.shape == t["table"].shape
+    np.testing.assert_allclose(tab_c, t["table"], rtol=4e-16, atol=0)          # within 1-2 ulp, not necessarily equal
+    assert np.array_equal(sid_c, t["table"][:, cols.index("subject_id")])
+    try:
+        pq = str(tmp_path / "frame.parquet")
+        df.to_parquet(pq)
+    except ImportError:
+        pytest.skip("no parquet engine importable")
+    tab_p, names_p, sid_p = GlucoseDataset.read_frame(pq)
+    assert names_p == cols and np.array_equal(tab_p, t["table"]) and np.array_equal(sid_p, sid_c)
+    # shuffled subjects come back in groupby order, rows of a subject in file order (stable)
+    perm = np.random.default_rng(0).permutation(len(df))
+    df.iloc[perm].to_parquet(pq)
+    tab_s, _, sid_s = GlucoseDataset.read_frame(pq)
+    assert (np.diff(sid_s) >= 0).all()
+    want = t["table"][perm][np.argsort(t["table"][perm][:, cols.index("subject_id")], kind="stable")]
+    assert np.array_equal(tab_s, want)
+    with pytest.raises(ValueError):
+        GlucoseDataset.read_frame(str(tmp_path / "frame.txt"))
+    # the oracle's windows on either frame: statistics agree to 1e-12 (the bar the GPU test uses), z-scores to 1 fp32 ulp
+    w = {}
+    for key, tab in (("csv", tab_c), ("pq", tab_p)):
+        frame, off = frame_from_table(tab, cols)
+        w[key] = fourgi.windows(frame, off, 20, 10, True)
+    np.testing.assert_allclose(w["csv"]["std"], w["pq"]["std"], rtol=1e-12)
+    np.testing.assert_allclose(w["csv"]["mean"], w["pq"]["mean"], rtol=1e-12)
+    np.testing.assert_allclose(w["csv"]["states"], w["pq"]["states"], rtol=2e-7, atol=1e-7)
+
+
 # ---- host mirror, no GPU --------------------------------------------------------------------------------------
 def test_mirror_parameters_match_reference_values():
     from hode.datagen import FourGIModel, grid_points

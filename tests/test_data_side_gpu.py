@@ -158,7 +158,16 @@ def test_k8_windows_vs_reference_dataset(golden_dir, name, src, tmp_path):
         except ImportError:                    # no parquet engine importable on this box: nothing to read back
             return
         ds2 = GlucoseDataset(pq, sequence_length=int(g["seq_len"]), stride=int(g["stride"]), normalize=bool(g["normalize"]))
-        assert torch.equal(ds2._states, ds._states) and np.array_equal(ds2.state_std, ds.state_std)
+        # NOT bitwise against the CSV dataset: pandas' default float parser (the one the reference uses,
+        # train_hybrid.py:64-67) is 1 ulp off on ~8 % of the values, parquet is exact.  Both must match the reference.
+        assert len(ds2) == len(ds)
+        np.testing.assert_allclose(ds2.state_mean, g["state_mean"], rtol=1e-12)
+        np.testing.assert_allclose(ds2.state_std, g["state_std"], rtol=1e-12)
+        np.testing.assert_allclose(ds2.state_std, ds.state_std, rtol=1e-12)
+        b2 = ds2.batch(np.arange(len(ds2)))
+        np.testing.assert_allclose(b2["observations"].cpu().numpy(), g["observations"], rtol=2e-7, atol=1e-7)
+        assert np.array_equal(b2["time_points"].cpu().numpy(), g["time_points"])
+        assert np.array_equal(b2["external_inputs"]["meal"].cpu().numpy(), g["meal"])
 
 
 def test_k8_vs_oracle_random_frames_and_edges():

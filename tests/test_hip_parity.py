@@ -125,7 +125,7 @@ def test_solve_fwd_batched_time_small_network(hode, golden_dir, g0_small):
     assert rel(s.y.cpu().numpy(), g["y_f64_converged_first4"]) < 1e-6
 
 
-def test_solve_fwd_rk4_config1(hode, g0):
+def test_cfg1_rk4_pure_odecore_fp64_32_patients(hode, g0):
     """BASELINE config 1: 32 patients, fixed-step RK4, pure ODECore (--no-nn: MLP zeroed), fp64."""
     rng = np.random.default_rng(0)
     B, T = 32, 241
@@ -427,7 +427,7 @@ def test_constant_inputs_and_gd_through_solve(hode, golden_dir, g0):
     assert relnorm(gode.cpu().numpy(), rode) < 1e-7
 
 
-def test_full_size_properties(hode, g0):
+def test_cfg2_forward_4096x241_fp32_properties(hode, g0):
     """BASELINE config[1] size (4 096 x 241, fp32): properties that do not need the oracle at full size.
     (i) bit-reproducible run to run, (ii) trajectories are independent: any sub-batch gives bitwise the same
     rows, (iii) the oracle agrees on a 32-patient sample, (iv) gradients add over a split of the batch."""
@@ -527,7 +527,7 @@ def test_mse_unaligned_and_rk4_budget(hode, g0):
     assert torch.isfinite(gx0).all() and torch.isfinite(gnn).all()
 
 
-def test_largest_baseline_cohort_on_one_gpu(hode):
+def test_cfg4_65536_cohort_and_its_8_rank_shards(hode):
     """BASELINE config 4 is a 65 536-patient cohort (8 192 per GPU on 8 GPUs).  The whole cohort also fits one GPU:
     every trajectory succeeds and the per-GPU shards of the 8-rank split reproduce the corresponding rows bitwise
     (patient sharding changes nothing numerically: there is no cross-trajectory coupling)."""

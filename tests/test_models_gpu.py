@@ -279,7 +279,7 @@ def test_forward_with_params_and_param_sets(M, golden_dir):
     assert float(m.ode_core.k_L) == pytest.approx(0.02)
 
 
-def test_elbo_value_and_reparameterised_gradient(M):
+def test_cfg5_elbo_value_and_reparameterised_gradient(M):
     """BASELINE config 5 (VI): S Monte-Carlo parameter draws x B patients in ONE launch, KL in fp64, and a
     reparameterised gradient through the adjoint (the reference's likelihood term carries none).
     Checks: value == per-sample forward_with_params evaluation; d ELBO / d mu matches central differences
@@ -359,7 +359,7 @@ def test_sobol_style_one_patient_per_parameter_set(M, golden_dir):
     assert float((ys[0] - ys[1]).abs().max()) > 1e-3
 
 
-def test_fused_train_step_matches_class_path(M, golden_dir):
+def test_cfg3_fused_train_step_matches_class_path(M, golden_dir):
     """The fused pipeline of bench.py / hode.train (solve with tape -> fused MSE -> adjoint -> clip+Adam kernels)
     makes the same parameter update as the drop-in class path (HybridODENN.loss(data term) -> autograd ->
     clip_grad_norm_ -> torch.optim.Adam), and the loss goes down over a few steps."""
