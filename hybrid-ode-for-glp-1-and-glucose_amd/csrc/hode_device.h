@@ -213,12 +213,16 @@ template <typename R> __device__ __forceinline__ void tableau_rowsT_store(R *row
 // ------------------------------------------------------------------------------------------
 // MLP parameters of ONE parameter set, register-resident.  NL = number of hidden layers (1..4).
 // Lane j owns hidden unit j of every layer.  H < 64 is zero-padded (relu(0) = 0 keeps it exact).
+__device__ __forceinline__ float mlp_hidden(const float (&w)[64], float bias, float h);
+__device__ __forceinline__ double mlp_hidden(const double (&w)[64], double bias, double h);
 template <typename R, int NL> struct MlpRegs {
     R w1[9];                          // W1[j][0..8]
     R b[NL];                          // b_l[j]
     R wh[(NL > 1) ? NL - 1 : 1][kMaxH]; // W_l[j][0..63], l = 2..NL
     R w5[6];                          // Wout[o][j]
     R b5;                             // lane l: bout[l & 7] (0 for slots 6,7)
+    // pre-activation of hidden layer l + 2 (l is a compile-time constant at every call site: unrolled layer loop)
+    __device__ __forceinline__ R hidden(int l, R h) const { return mlp_hidden(wh[l], b[l + 1], h); }
 };
 
 __host__ __device__ inline int nn_param_count(int H, int L) { return 9 * H + H + (L - 1) * (H * H + H) + 6 * H + 6; }
@@ -240,6 +244,29 @@ constexpr int kStageElems = (kMaxH / 2) * kStageStride;      // two passes of 32
 // may be nullptr for fp64): every lane reads its weight row with coalesced 16-byte loads, drops it into LDS
 // and reads it back in the lane-dependent rotated order -- no per-lane gather from global memory (which
 // cost 630 B/lane of scratch spills = 170 MB of extra HBM traffic per launch) and no long-lived temporaries.
+// first / last layer weights and all biases ("edge" parameters) of one parameter set -> registers of lane j
+template <typename R, int NL, typename WT>
+__device__ __forceinline__ void mlp_load_edges(WT &W, const R *__restrict__ p, int H, int lane)
+{
+    const R live = (lane < H) ? R(1) : R(0);
+    const int j = (lane < H) ? lane : H - 1;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) W.w1[i] = live * p[j * 9 + i];
+    p += 9 * H;
+    W.b[0] = live * p[j];
+    p += H;
+#pragma unroll
+    for (int l = 0; l < NL - 1; ++l) {
+        p += (size_t)H * H;
+        W.b[l + 1] = live * p[j];
+        p += H;
+    }
+#pragma unroll
+    for (int o = 0; o < 6; ++o) W.w5[o] = live * p[o * H + j];
+    p += 6 * H;
+    W.b5 = ((lane & 7) < 6) ? p[((lane & 7) < 6) ? (lane & 7) : 0] : R(0);   // replicated per 8-lane group
+}
+
 template <typename R, int NL>
 __device__ __forceinline__ void mlp_load(MlpRegs<R, NL> &W, const R *__restrict__ p, int H, int lane, R *stage)
 {
@@ -403,6 +430,73 @@ __device__ __forceinline__ double mlp_hidden(const double (&w)[kMaxH], double bi
     return acc0 + acc1;
 }
 
+// ---- hidden matrices in a workgroup-shared LDS image (forward solve, fp32) ---------------------------------------
+// 211 weight registers per wave cap the register-resident forward kernel at 2 waves per SIMD, where the ~200 plain
+// (2-cycle) VALU instructions of the per-RHS fixed part cannot overlap: one wave issues at most one VALU per 4 cycles.
+// The image keeps the SAME rotating-operand order, four weights per 16-byte word:
+//     img[l][n][lane j] = { W_l[j][16 q + ((j - n) & 15)] : q = 0..3 }          (n = 0..15)
+// i.e. exactly the operands of FMA group n of mlp_hidden_step, so the arithmetic (and its order) is bit-identical to the
+// register kernel; a layer is 16 conflict-free ds_read_b128 + 64 v_fmac_f32_dpp.  NREG of the NL-1 matrices may still be
+// copied to registers (fewer LDS reads, fewer waves): the LDS pipe moves 256 B/clk per CU, four SIMDs of DPP FMAs
+// fed from LDS alone would ask for 244 B/clk.
+constexpr int kImgVec = 16 * kWave;                     // float4 words per hidden matrix
+__device__ __forceinline__ void wimg_store(float *__restrict__ img, const float *__restrict__ nn_p, int H, int NLm1, int tid,
+                                           int nthreads)
+{
+    const float *Wl = nn_p + 9 * H + H;
+    for (int l = 0; l < NLm1; ++l) {
+        for (int i = tid; i < kMaxH * kMaxH; i += nthreads) {
+            const int q = i & 3, j = (i >> 2) & 63, n = i >> 8;
+            const int col = 16 * q + ((j - n) & 15);
+            img[(size_t)l * kMaxH * kMaxH + i] = (j < H && col < H) ? Wl[(size_t)j * H + col] : 0.f;
+        }
+        Wl += (size_t)H * H + H;
+    }
+}
+template <int N>
+__device__ __forceinline__ void mlp_hidden_lds_step(const float4 *__restrict__ img, int lane, const float (&R)[4], float (&acc)[4])
+{
+    const float4 w = img[N * kWave + lane];
+    acc[0] = fmac_ror<N>(acc[0], R[0], w.x);
+    acc[1] = fmac_ror<N>(acc[1], R[1], w.y);
+    acc[2] = fmac_ror<N>(acc[2], R[2], w.z);
+    acc[3] = fmac_ror<N>(acc[3], R[3], w.w);
+    if constexpr (N < 15) mlp_hidden_lds_step<N + 1>(img, lane, R, acc);
+}
+__device__ __forceinline__ float mlp_hidden_lds(const float4 *__restrict__ img, int lane, float bias, float h)
+{
+    float R[4];
+    rows_replicate(h, R);
+    float acc[4] = {bias, 0.f, 0.f, 0.f};
+    mlp_hidden_lds_step<0>(img, lane, R, acc);
+    return (acc[0] + acc[1]) + (acc[2] + acc[3]);
+}
+template <int NL, int NREG> struct MlpLds {
+    static_assert(NREG >= 0 && NREG <= ((NL > 1) ? NL - 1 : 0), "NREG counts hidden matrices");
+    float w1[9];
+    float b[NL];
+    float w5[6];
+    float b5;
+    float whr[(NREG > 0) ? NREG : 1][kMaxH];      // the first NREG hidden matrices, register-resident
+    const float4 *img;                            // all NL-1 matrices (LDS)
+    int lane;
+    __device__ __forceinline__ void load_regs()
+    {
+#pragma unroll
+        for (int l = 0; l < NREG; ++l)
+#pragma unroll
+            for (int n = 0; n < 16; ++n) {
+                const float4 w = img[(l * 16 + n) * kWave + lane];
+                whr[l][n] = w.x; whr[l][16 + n] = w.y; whr[l][32 + n] = w.z; whr[l][48 + n] = w.w;
+            }
+    }
+    __device__ __forceinline__ float hidden(int l, float h) const
+    {
+        if (l < NREG) return mlp_hidden(whr[(l < NREG) ? l : 0], b[l + 1], h);
+        return mlp_hidden_lds(img + (size_t)l * kImgVec, lane, b[l + 1], h);
+    }
+};
+
 // dW[j][k] += d_j * h_k in the register order of the weights (rotated for fp32, natural for fp64)
 template <int N> __device__ __forceinline__ void mlp_outer_step(float (&gw)[kMaxH], float d, const float (&R)[4])
 {
@@ -432,8 +526,9 @@ template <typename R, int NL> struct MlpActs { R h[NL]; };
 //   Y   lane-distributed state: lane l holds x_{l&7} (replicated over the eight 8-lane groups;
 //       only lanes 0..5 are read)
 //   returns the derivative in the same replicated layout (component slots 6,7 hold 0)
-template <typename R, int NL, bool KEEP>
-__device__ __forceinline__ R rhs_eval(const MlpRegs<R, NL> &W, const OdeP<R> &o, R t, R Y, R meal, R tvns,
+//   W   weights holder: MlpRegs (everything in VGPRs) or MlpLds (hidden matrices in a workgroup-shared LDS image)
+template <typename R, int NL, bool KEEP, typename WT>
+__device__ __forceinline__ R rhs_eval(const WT &W, const OdeP<R> &o, R t, R Y, R meal, R tvns,
                                       R gde /* Hill term, 0 without GD */, int lane, MlpActs<R, NL> *acts)
 {
     const R G = lane_bcast(Y, 0), I = lane_bcast(Y, 1), Glu = lane_bcast(Y, 2), GLP1 = lane_bcast(Y, 3),
@@ -463,7 +558,7 @@ __device__ __forceinline__ R rhs_eval(const MlpRegs<R, NL> &W, const OdeP<R> &o,
     if constexpr (KEEP) acts->h[0] = h;
 #pragma unroll
     for (int l = 0; l < NL - 1; ++l) {
-        h = rmax0(mlp_hidden(W.wh[l], W.b[l + 1], h));
+        h = rmax0(W.hidden(l, h));
         if constexpr (KEEP) acts->h[l + 1] = h;
     }
     R p[6];

@@ -1,25 +1,14 @@
-// hode_solve_fwd.hip -- K2+K3: batched forward integration, one trajectory per wavefront.
+// hode_solve_fwd.hip -- K2+K3: batched forward integration, one trajectory per wavefront, ALL weights in registers.
 //
-// Replaces HybridODENN.forward (reference models/hybrid_ode_nn.py:136-261): the per-patient
-// scipy.integrate.solve_ivp loop, the RHS round trip through NumPy and the input interpolation.
-// Integrator = SciPy RK45's controller (scipy/integrate/_ivp/rk.py:111-176) with every grid
-// point a mandatory step boundary (the meal forcing is piecewise linear with kinks there,
-// SURVEY.md F6/F7); FSAL derivative and step-size proposal are carried across grid points.
-// The CPU restatement of exactly this algorithm is oracle/hode_oracle_impl.h (hode_oracle_solve).
-#include "hode_device.h"
-#include "hode_kernels.h"
+// Replaces HybridODENN.forward (reference models/hybrid_ode_nn.py:136-261).  The integration itself is
+// hode_solve_body.h (solve_one).  This kernel -- one wave per workgroup, 211 weight registers, 2 waves per SIMD -- is the
+// production kernel for fp32 and fp64.  HODE_FWD=wg selects the workgroup kernel of hode_solve_fwd_wg.hip instead (hidden
+// matrices in a shared LDS image, 4 waves per SIMD): same bits, measured 8-12 % SLOWER, kept as the
+// reproducible record of that experiment.
+#include "hode_solve_body.h"
+#include <cstdlib>
 
 namespace hode {
-
-template <typename R> __device__ __forceinline__ R inp_at(const R *__restrict__ p, int mode, int b, int T, int k)
-{
-    if (mode == 0) return R(0);
-    return (mode == 1) ? p[b] : p[(size_t)b * T + k];
-}
-
-template <typename R> struct Eps;
-template <> struct Eps<float> { static constexpr float v = 1.1920929e-7f; };
-template <> struct Eps<double> { static constexpr double v = 2.220446049250313e-16; };
 
 template <typename R, int NL, int METHOD, int LB, bool TAPE, bool GD>
 __global__ __launch_bounds__(64, LB) void solve_fwd_kernel(const SolveArgs<R> a)
@@ -29,9 +18,7 @@ __global__ __launch_bounds__(64, LB) void solve_fwd_kernel(const SolveArgs<R> a)
     __shared__ R ybuf[kWave + 8];             // output staging: rows of 6 reals are gathered into 256-byte stores
     __shared__ R wstage[(sizeof(R) == 4) ? kStageElems : 1];   // weight-row permutation scratch (prologue only)
     const int lane = threadIdx.x;
-    const int c8 = lane & 7, grp = lane >> 3;
     const int b = blockIdx.x;                 // one wave == one trajectory
-    const int T = a.T;
     const int set = b / (a.B / a.n_sets);
 
     tableau_rows_store<R>(rows, METHOD, lane, 64);
@@ -41,195 +28,7 @@ __global__ __launch_bounds__(64, LB) void solve_fwd_kernel(const SolveArgs<R> a)
     OdeP<R> o;
     ode_load(o, a.ode_p + 17 * set);
     __syncthreads();
-
-    const R *__restrict__ tg = a.t + (a.t_batched ? (size_t)b * T : 0);
-    R *__restrict__ yb = a.y + (size_t)b * T * 6;
-    R *__restrict__ tape = TAPE ? a.tape + (size_t)b * a.max_steps * 8 : nullptr;
-    int *__restrict__ tseg = TAPE ? a.tape_seg + (size_t)b * a.max_steps : nullptr;
-    // stage tape: [step][stage 0..5][NL activations + stage state][64 lanes]
-    constexpr int kSlot = (NL + 1) * kWave;
-    R *__restrict__ stg = TAPE ? a.tape_stage + (size_t)b * a.max_steps * 6 * kSlot : nullptr;
-    constexpr bool use_gd = GD;               // the Hill term (two pow calls) only exists in the GD instantiation
-    const TableauData &tab = kTableau[METHOD];
-
-    // state, replicated over the eight 8-lane groups: lane l holds y_{l&7}
-    R Y = (c8 < 6) ? a.x0[(size_t)b * 6 + c8] : R(0);
-    // y[b, k, 0:6] is a contiguous stream of 6 T reals: rows are staged in LDS and leave as full 64-lane
-    // stores (a 24-byte store per grid point costs a partial cache line each: measured 1.9x write traffic)
-    int ypos = 0;                             // staged reals
-    size_t ybase = 0;                         // reals already written
-    auto y_put = [&](R v) {
-        if (lane < 6) ybuf[ypos + lane] = v;
-        ypos += 6;
-        if (ypos >= kWave) {
-            __builtin_amdgcn_wave_barrier();
-            yb[ybase + lane] = ybuf[lane];
-            const R carry = (lane < 8) ? ybuf[kWave + lane] : R(0);
-            __builtin_amdgcn_wave_barrier();
-            if (lane < 8) ybuf[lane] = carry;
-            ybase += kWave;
-            ypos -= kWave;
-        }
-    };
-    auto y_flush = [&]() {
-        __builtin_amdgcn_wave_barrier();
-        if (lane < ypos) yb[ybase + lane] = ybuf[lane];
-        ybase += ypos;
-        ypos = 0;
-    };
-    y_put(Y);
-
-    int st = HODE_ST_OK, ns = 0, nf = 0, k = 0;
-    R h_abs = R(0);
-    R KK = R(0);                              // packed stage derivatives: lanes 8s..8s+7 = K_{s+1}
-    bool have_f = false;
-
-    for (; k + 1 < T && st == HODE_ST_OK; ++k) {
-        const R t0 = tg[k], t1 = tg[k + 1];
-        const R m0 = inp_at(a.meal, a.meal_mode, b, T, k), m1 = inp_at(a.meal, a.meal_mode, b, T, k + 1);
-        const R v0 = inp_at(a.tvns, a.tvns_mode, b, T, k), v1 = inp_at(a.tvns, a.tvns_mode, b, T, k + 1);
-        const R d0 = inp_at(a.gd, a.gd_mode, b, T, k), d1 = inp_at(a.gd, a.gd_mode, b, T, k + 1);
-        const R len = t1 - t0;
-        if (!(len > R(0))) {                  // repeated grid time: copy the state
-            y_put(Y);
-            continue;
-        }
-        const R inv_len = first_lane(R(1) / len);
-        const R dm = first_lane(m1 - m0), dv = first_lane(v1 - v0), dd = first_lane(d1 - d0);
-        // piecewise-linear forcing on this interval (models/hybrid_ode_nn.py:217-229)
-        // slot >= 0 (TAPE): also record the layer activations and the stage state for the adjoint
-        auto f_at = [&](R ts, R Ys, int slot) -> R {
-            const R al = (ts - t0) * inv_len;
-            R gde = R(0);
-            if constexpr (use_gd) gde = gd_effect(o, rfma(al, dd, d0));
-            if constexpr (TAPE) {
-                MlpActs<R, NL> ac;
-                const R F = rhs_eval<R, NL, true>(W, o, ts, Ys, rfma(al, dm, m0), rfma(al, dv, v0), gde, lane, &ac);
-                if (slot >= 0 && slot < a.max_steps * 6) {
-                    R *dst = stg + (size_t)slot * kSlot + lane;
-#pragma unroll
-                    for (int l = 0; l < NL; ++l) dst[l * kWave] = ac.h[l];
-                    dst[NL * kWave] = Ys;
-                }
-                return F;
-            } else {
-                return rhs_eval<R, NL, false>(W, o, ts, Ys, rfma(al, dm, m0), rfma(al, dv, v0), gde, lane, nullptr);
-            }
-        };
-        auto tape_put = [&](R tc, R h) {
-            if constexpr (TAPE) {
-                // entry = {t, h, y0..y5}: lanes 0..5 store the state, lanes 6,7 store t and h
-                const R e = (lane < 6) ? Y : (lane == 6) ? tc : h;
-                if (lane < 8) tape[(size_t)ns * 8 + ((lane < 6) ? lane + 2 : lane - 6)] = e;
-                if (lane == 0) tseg[ns] = k;
-            }
-        };
-        R tc = t0;
-
-        if constexpr (METHOD == HODE_METHOD_RK4) {
-            if (ns >= a.max_steps) { st = HODE_ST_MAXSTEPS; break; }     // budget < T-1: report, never overrun the tape
-            const R hh = len;
-            KK = R(0);
-#pragma unroll 1
-            for (int s = 0; s < 4; ++s) {
-                const R Ys = rfma(hh, group_sum8(rows[s * kWave + lane] * KK), Y);
-                const R F = f_at(rfma((R)tab.c[s], hh, t0), Ys, ns * 6 + s);
-                KK = (grp == s) ? F : KK;
-            }
-            tape_put(t0, hh);
-            Y = rfma(hh, group_sum8(rows[7 * kWave + lane] * KK), Y);
-            nf += 4;
-            ns += 1;
-        } else {
-            if (!have_f) {
-                // first derivative + Hairer's initial step (scipy/integrate/_ivp/common.py:68-135)
-                const R K1 = f_at(t0, Y, 0);
-                const R sc = (c8 < 6) ? (a.atol + rabs(Y) * a.rtol) : R(1);
-                const R q0 = Y / sc, q1 = K1 / sc;
-                const float dn0 = sqrtf((float)first_lane(oct_allsum(q0 * q0)) / 6.0f);
-                const float dn1 = sqrtf((float)first_lane(oct_allsum(q1 * q1)) / 6.0f);
-                float h0 = (dn0 < 1e-5f || dn1 < 1e-5f) ? 1e-6f : 0.01f * dn0 / dn1;
-                h0 = fminf(h0, (float)len);
-                const R f1 = f_at(t0 + (R)h0, rfma((R)h0, K1, Y), -1);
-                const R q2 = (f1 - K1) / sc;
-                const float dn2 = sqrtf((float)first_lane(oct_allsum(q2 * q2)) / 6.0f) / h0;
-                const float h1 = (dn1 <= 1e-15f && dn2 <= 1e-15f) ? fmaxf(1e-6f, h0 * 1e-3f)
-                                                                   : powf(0.01f / fmaxf(dn1, dn2), 0.2f);
-                h_abs = first_lane((R)fminf(fminf(100.0f * h0, h1), (float)len));
-                KK = (grp == 0) ? K1 : R(0);
-                nf += 2;
-                have_f = true;
-            }
-            while (tc < t1 && st == HODE_ST_OK) {
-                bool rejected = false;
-                for (;;) {                     // scipy/integrate/_ivp/rk.py:126-176
-                    if (ns >= a.max_steps) { st = HODE_ST_MAXSTEPS; break; }
-                    const R min_step = R(10) * Eps<R>::v * (rabs(tc) > R(1e-30) ? rabs(tc) : R(1e-30));
-                    if (h_abs < min_step) { st = HODE_ST_UNDERFLOW; break; }
-                    R h = h_abs, tn = tc + h;
-                    bool clipped = false;
-                    if (tn >= t1 || (t1 - tn) < R(0.01) * h) { tn = t1; h = tn - tc; clipped = true; }
-                    h = first_lane(h);
-                    tn = first_lane(tn);
-                    KK = (grp == 0) ? KK : R(0);          // drop stale stages (0 * NaN would poison the sums)
-                    R Ys = Y, F = R(0);
-                    // the coefficient row and node of stage s+1 are fetched from LDS BEFORE the RHS of stage s,
-                    // so the LDS latency hides behind the MLP instead of opening every stage
-                    R coef = rows[1 * kWave + lane], cs = cvec[1];
-#pragma unroll 1
-                    for (int s = 1; s <= 6; ++s) {        // stages 2..6 and the FSAL stage (row 6 = 5th-order weights)
-                        Ys = rfma(h, group_sum8(coef * KK), Y);
-                        const R ts = (s >= 5) ? tn : rfma(cs, h, tc);
-                        coef = rows[(s + 1) * kWave + lane];   // s = 6 fetches row 7 = error weights
-                        cs = cvec[(s + 1) & 7];
-                        // stage s of this step; the FSAL stage (s == 6) is stage 0 of the NEXT step
-                        F = f_at(ts, Ys, (s < 6) ? ns * 6 + s : (ns + 1) * 6);
-                        KK = (grp == s) ? F : KK;
-                    }
-                    const R Yn = Ys;                      // 5th-order solution
-                    nf += 6;
-                    const R err = h * group_sum8(coef * KK);
-                    const R ymax = rabs(Y) > rabs(Yn) ? rabs(Y) : rabs(Yn);
-                    const R qe = (c8 < 6) ? err / (a.atol + ymax * a.rtol) : R(0);
-                    float en = sqrtf((float)first_lane(oct_allsum(qe * qe)) / 6.0f);
-                    const float ysum = (float)first_lane(oct_allsum(Yn));
-                    if (!(en == en) || !(fabsf(ysum) <= 3.0e38f) || !(fabsf(en) <= 3.0e38f)) en = 1e30f;
-                    if (en < 1.0f) {
-                        float fac = (en == 0.0f) ? 10.0f : fminf(10.0f, 0.9f * __builtin_exp2f(-0.2f * __builtin_log2f(en)));
-                        if (rejected) fac = fminf(1.0f, fac);
-                        tape_put(tc, h);
-                        const R hn = h * (R)fac;
-                        h_abs = first_lane((clipped && hn < h_abs) ? h_abs : hn);   // a clipped step never shrinks the proposal
-                        Y = Yn;
-                        KK = (grp == 0) ? F : KK;         // FSAL: K7 becomes K1
-                        tc = tn;
-                        ns++;
-                        break;
-                    } else {
-                        h_abs = first_lane(h * (R)fmaxf(0.2f, 0.9f * __builtin_exp2f(-0.2f * __builtin_log2f(en))));
-                        rejected = true;
-                        if (en >= 1e30f && !(h_abs > min_step)) { st = HODE_ST_NONFINITE; break; }
-                    }
-                }
-            }
-        }
-        if (st == HODE_ST_OK) {
-            const float ysum = (float)first_lane(oct_allsum(Y));
-            if (!(fabsf(ysum) <= 3.0e38f)) st = HODE_ST_NONFINITE;
-            else y_put(Y);
-        }
-        if (st != HODE_ST_OK) break;
-    }
-    y_flush();
-    if (st != HODE_ST_OK) {
-        // rows from the failed interval on stay zero (models/hybrid_ode_nn.py:243-256)
-        for (size_t i = ybase + lane; i < (size_t)T * 6; i += kWave) yb[i] = R(0);
-    }
-    if (lane == 0) {
-        a.status[b] = st;
-        if (a.nsteps) a.nsteps[b] = ns;
-        if (a.nfev) a.nfev[b] = nf;
-    }
+    solve_one<R, NL, METHOD, TAPE, GD>(a, b, W, o, rows, cvec, ybuf, lane);
 }
 
 template <typename R, int NL, int METHOD, bool TAPE, bool GD>
@@ -254,8 +53,18 @@ static int launch_nl(hipStream_t s, const SolveArgs<R> &a, int method)
     return hipGetLastError() == hipSuccess ? HODE_OK : HODE_ELAUNCH;
 }
 
+// HODE_FWD=wg: the workgroup kernel (hode_solve_fwd_wg.hip) for comparison
+static bool fwd_use_wg()
+{
+    static const bool v = [] { const char *e = getenv("HODE_FWD"); return e && e[0] == 'w'; }();
+    return v;
+}
+
 template <typename R> int launch_solve_fwd(hipStream_t s, const SolveArgs<R> &a, int L, int method)
 {
+    if constexpr (sizeof(R) == 4) {
+        if (L >= 2 && L <= 4 && fwd_use_wg()) return launch_solve_fwd_wg(s, a, L, method);
+    }
     switch (L) {
     case 1: return launch_nl<R, 1>(s, a, method);
     case 2: return launch_nl<R, 2>(s, a, method);

@@ -543,3 +543,40 @@ def test_cfg4_65536_cohort_and_its_8_rank_shards(hode):
         assert hi - lo == 8192
         shard = hode.solve_fwd(x0[lo:hi], t, meal[lo:hi], tv[lo:hi], None, ode, nn, 64, 4)
         assert torch.equal(shard.y, full.y[lo:hi])
+
+
+def test_fwd_workgroup_kernel_is_bitwise_the_register_kernel(hode, golden_dir, g0, tmp_path):
+    """HODE_FWD=wg (hidden matrices in a shared LDS image, 16 waves per workgroup; hode_solve_fwd_wg.hip) runs the same
+    arithmetic in the same order as the production kernel: identical bits, with and without a tape, ragged batch,
+    two parameter sets.  (The switch is read once per process, so the variant runs in a child process.)"""
+    import subprocess
+    import sys
+    g = np.load(os.path.join(golden_dir, "g4_t61_pulses.npz"))
+    out = str(tmp_path / "wg.npz")
+    code = f"""
+import sys, numpy as np, torch
+sys.path.insert(0, {os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "hybrid-ode-for-glp-1-and-glucose_amd")!r})
+import hode
+g = np.load({os.path.join(golden_dir, "g4_t61_pulses.npz")!r}); w = np.load({os.path.join(golden_dir, "g0_weights_h64_l4.npz")!r})
+f = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.float32, device="cuda")
+x0 = f(np.concatenate([g["x0"]] * 5)[:38]); meal = f(np.concatenate([g["meal"]] * 5)[:38]); tv = f(np.concatenate([g["tvns"]] * 5)[:38])
+nn2 = torch.cat([f(w["nn_flat"]), 0.5 * f(w["nn_flat"])]); ode2 = torch.cat([f(w["ode"]), f(w["ode"])])
+a = hode.solve_fwd(x0, f(g["t"]), meal, tv, None, ode2, nn2, 64, 4, n_sets=2)
+b = hode.solve_fwd(x0, f(g["t"]), meal, tv, None, ode2, nn2, 64, 4, n_sets=2, want_tape=True)
+gx0, gnn, _ = hode.solve_bwd(b, torch.ones_like(b.y))
+np.savez({out!r}, y=a.y.cpu().numpy(), yt=b.y.cpu().numpy(), nfev=a.nfev.cpu().numpy(), gnn=gnn.cpu().numpy())
+"""
+    ys = {}
+    for mode in ("regs", "wg"):
+        env = dict(os.environ, HODE_FWD=mode)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        ys[mode] = dict(np.load(out))
+    for k in ("y", "yt", "nfev"):
+        assert np.array_equal(ys["regs"][k], ys["wg"][k]), k
+    assert np.array_equal(ys["regs"]["y"], ys["regs"]["yt"])
+    # the adjoint consumes the stage tape either kernel wrote: same tape, same gradient up to the atomics' summation order
+    assert relnorm(ys["wg"]["gnn"], ys["regs"]["gnn"]) < 1e-5
+    ref = O.solve(np.concatenate([g["x0"]] * 5)[:19], g["t"], np.concatenate([g["meal"]] * 5)[:19], np.concatenate([g["tvns"]] * 5)[:19],
+                  None, g0["ode"], g0["nn"], 64, 4, dtype=np.float32)
+    assert rel(ys["wg"]["y"][:19], ref.y) < 2e-5
