@@ -13,7 +13,7 @@ template <typename R> struct SolveArgs {
     R *y;
     int32_t *status, *nsteps, *nfev;
     R *tape;            // [B][max_steps][8] = {t, h, y0..y5}
-    int32_t *tape_seg;  // [B][max_steps] grid interval of each accepted step
+    int32_t *tape_seg;  // [B][max_steps] grid interval of each accepted step (| kSegClosed)
     R *tape_stage;      // [B][max_steps][6 stages][L+1][64]: layer activations + stage state of every accepted step
     int L;
 };
@@ -80,6 +80,9 @@ int launch_4gi_rhs(hipStream_t s, int B, int hv, const FourGIPar &p, const doubl
                    double *d);
 int launch_4gi_windows(hipStream_t s, const WinArgs &a, int normalize, double *mean_std, void *scratch);
 int launch_4gi_window_moments(hipStream_t s, const WinArgs &a, double *moments, void *scratch);
+
+// interval index of an accepted step on the tape: bit 30 set = the step ended exactly on the grid point closing its interval
+constexpr int kSegClosed = 1 << 30;
 
 // tape = entries | interval indices | (256-byte aligned) stage tape
 inline size_t tape_seg_offset(int B, int max_steps, size_t elem) { return (size_t)B * max_steps * 8 * elem; }

@@ -2,7 +2,7 @@
 //
 // K6 replaces torch.nn.utils.clip_grad_norm_(model.parameters(), 5.0) + torch.optim.Adam.step()
 // (reference train/train_hybrid.py:255-261, 438-441).  The parameter vector is tiny (13 510
-// floats = 54 KB): two launches on one stream -- squared-norm reduction, then the update that
+// floats = 54 KB): two launches on one stream -- squared-norm reduction (one workgroup, fixed summation order), then the update that
 // reads the norm from device memory -- no host synchronisation, graph-capturable.
 // The MSE pass replaces F.mse_loss(predictions, observations) and its autograd
 // (models/hybrid_ode_nn.py:294): one read of y and obs, one write of dLoss/dy; HBM-bound,
@@ -12,15 +12,27 @@
 
 namespace hode {
 
-__global__ __launch_bounds__(256) void sqnorm_kernel(int64_t n, const float *__restrict__ g, float scale, float *out)
+// Squared gradient norm, DETERMINISTIC: one workgroup, every thread sums its strided elements in index order, a fixed
+// butterfly inside each wave, then thread 0 adds the 16 wave sums in wave order.  No atomics, so the clip coefficient is
+// the same bits on every rank and in every run (data-parallel replicas stay identical without a parameter broadcast).
+// 13 510 parameters = 13 elements per thread: the launch is latency, not bandwidth.
+__global__ __launch_bounds__(1024) void sqnorm_kernel(int64_t n, const float *__restrict__ g, float scale, float *out)
 {
+    __shared__ float part[16];
     float acc = 0.f;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t i = threadIdx.x; i < n; i += 1024) {
         const float v = g[i] * scale;
         acc = rfma(v, v, acc);
     }
     acc = wave_allsum(acc);
-    if ((threadIdx.x & 63) == 0) atomic_add(out, acc);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) t += part[w];
+        *out = t;
+    }
 }
 
 __global__ __launch_bounds__(256) void adam_kernel(int64_t n, float *__restrict__ p, const float *__restrict__ g,
@@ -57,7 +69,7 @@ int launch_adam(hipStream_t s, int64_t n, float *p, const float *g, float *m, fl
     if (blocks > 1024) blocks = 1024;
     float *sq = (float *)scratch;
     if (hipMemsetAsync(sq, 0, 8, s) != hipSuccess) return HODE_ELAUNCH;
-    if (max_norm > 0.f) hipLaunchKernelGGL(sqnorm_kernel, dim3(blocks), dim3(256), 0, s, n, g, grad_scale, sq);
+    if (max_norm > 0.f) hipLaunchKernelGGL(sqnorm_kernel, dim3(1), dim3(1024), 0, s, n, g, grad_scale, sq);
     const float bc1 = 1.f - powf(b1, (float)step), bc2 = 1.f - powf(b2, (float)step);
     hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, s, n, p, g, m, v, lr, b1, b2, eps, bc1, bc2, max_norm,
                        grad_scale, wd, sq);

@@ -106,12 +106,14 @@ __device__ __forceinline__ void solve_one(const SolveArgs<R> &a, const int b, co
                 return rhs_eval<R, NL, false>(W, o, ts, Ys, rfma(al, dm, m0), rfma(al, dv, v0), gde, lane, nullptr);
             }
         };
-        auto tape_put = [&](R tc, R h) {
+        // `closes`: the step ends exactly on the grid point t1 (bit 30 of the interval index; the adjoint needs it to know
+        // which grid rows a FAILED trajectory still wrote)
+        auto tape_put = [&](R tc, R h, bool closes) {
             if constexpr (TAPE) {
                 // entry = {t, h, y0..y5}: lanes 0..5 store the state, lanes 6,7 store t and h
                 const R e = (lane < 6) ? Y : (lane == 6) ? tc : h;
                 if (lane < 8) tape[(size_t)ns * 8 + ((lane < 6) ? lane + 2 : lane - 6)] = e;
-                if (lane == 0) tseg[ns] = k;
+                if (lane == 0) tseg[ns] = k | (closes ? kSegClosed : 0);
             }
         };
         R tc = t0;
@@ -126,7 +128,7 @@ __device__ __forceinline__ void solve_one(const SolveArgs<R> &a, const int b, co
                 const R F = f_at(rfma((R)tab.c[s], hh, t0), Ys, ns * 6 + s);
                 KK = (grp == s) ? F : KK;
             }
-            tape_put(t0, hh);
+            tape_put(t0, hh, true);
             Y = rfma(hh, group_sum8(rows[7 * kWave + lane] * KK), Y);
             nf += 4;
             ns += 1;
@@ -187,7 +189,7 @@ __device__ __forceinline__ void solve_one(const SolveArgs<R> &a, const int b, co
                     if (en < 1.0f) {
                         float fac = (en == 0.0f) ? 10.0f : fminf(10.0f, 0.9f * __builtin_exp2f(-0.2f * __builtin_log2f(en)));
                         if (rejected) fac = fminf(1.0f, fac);
-                        tape_put(tc, h);
+                        tape_put(tc, h, clipped);
                         const R hn = h * (R)fac;
                         h_abs = first_lane((clipped && hn < h_abs) ? h_abs : hn);   // a clipped step never shrinks the proposal
                         Y = Yn;

@@ -144,10 +144,22 @@ __global__ __launch_bounds__(WTREG ? 256 : 64 * kBwdWaves, (sizeof(R) == 4 && !W
         if (n > 0) rec_dma(stg + ((size_t)(n - 1) * 6 + (S - 1)) * kSlot, rec);
 #pragma unroll 1
         for (int st = n - 1; st >= 0; --st) {
-            const int k = tseg[st];
-            // cotangents of the grid rows this step produced (row k+1 and any repeated rows).  A failed
-            // trajectory's unfinished last interval was never written to y: it injects nothing.
-            const int hi = (st == n - 1) ? (ok ? T - 1 : k) : knext;
+            const int kraw = tseg[st];
+            const int k = kraw & (kSegClosed - 1);
+            // cotangents of the grid rows this step produced (row k+1 and any repeated rows that follow it).  The last step
+            // of a FAILED trajectory: if it closed its interval, row k+1 and the copies behind it (zero-length intervals up
+            // to the interval that failed) were still written; if it did not, nothing after row k was.
+            int hi = knext;
+            if (st == n - 1) {
+                hi = T - 1;
+                if (!ok) {
+                    hi = k;
+                    if (kraw & kSegClosed) {
+                        hi = k + 1;
+                        while (hi + 1 < T && !(tg[hi + 1] > tg[hi])) ++hi;
+                    }
+                }
+            }
             for (int r = k + 1; r <= hi; ++r) {
                 // six wave-uniform (scalar) loads + selects: vector-memory traffic stays reserved for the DMAs
                 const R *__restrict__ gr = gyb + (size_t)r * 6;
@@ -190,7 +202,17 @@ __global__ __launch_bounds__(WTREG ? 256 : 64 * kBwdWaves, (sizeof(R) == 4 && !W
             }
             lam += group_sum8(rowsT[7 * kWave + lane] * ZZ);
         }
-        if (lane < 6) a.gx0[(size_t)b * 6 + lane] = lam + gyb[lane];
+        // rows 1..kf are copies of x0 (the grid starts with repeated times; kf = first interval of positive length, which is
+        // also the interval of step 0 and the interval a trajectory without any accepted step failed in): their
+        // cotangents go straight to gx0, next to row 0's
+        int kf = 0;
+        while (kf + 1 < T && !(tg[kf + 1] > tg[kf])) ++kf;
+        for (int r = 0; r <= kf; ++r) {
+            const R *__restrict__ gr = gyb + (size_t)r * 6;
+            const R g0 = gr[0], g1 = gr[1], g2 = gr[2], g3 = gr[3], g4 = gr[4], g5 = gr[5];
+            lam += (c8 == 0) ? g0 : (c8 == 1) ? g1 : (c8 == 2) ? g2 : (c8 == 3) ? g3 : (c8 == 4) ? g4 : (c8 == 5) ? g5 : R(0);
+        }
+        if (lane < 6) a.gx0[(size_t)b * 6 + lane] = lam;
     }
 
     if (a.gnn) {

@@ -78,25 +78,98 @@ def _tape_budget(dev):
     return max(1, min(TAPE_BUDGET_BYTES, int(0.8 * (free + reusable))))
 
 
-def _tape_steps(T, method):
-    return max(T - 1, 1) if method == hode.METHOD_RK4 else (T - 1) + max(32, (T - 1) // 4)
+# Accepted-step budget of a solve that records a tape: every step costs 6*(L+1)*256 B of stage tape, so the default is
+# T-1 (one step per interval, what the benchmark regime takes) plus a margin.  `TAPE_STEP_MARGIN` / the `tape_steps`
+# attribute of a model change it; a trajectory that STILL needs more steps (stiff or z-scored data) is not lost: it is
+# integrated again with the no-grad budget in a second, small launch (_solve_taped), so a solve under autograd returns
+# the same status as the same solve under torch.no_grad().
+TAPE_STEP_MARGIN = (32, 4)        # steps = (T-1) + max(margin[0], (T-1) // margin[1])
+
+
+def _tape_steps(T, method, override=None):
+    if method == hode.METHOD_RK4:
+        return max(T - 1, 1)
+    if override is not None:
+        return max(int(override), 1)
+    return (T - 1) + max(TAPE_STEP_MARGIN[0], (T - 1) // TAPE_STEP_MARGIN[1])
+
+
+def _eval_steps(T, method):
+    return max(T - 1, 1) if method == hode.METHOD_RK4 else 8 * (T - 1) + 64
+
+
+class _Taped:
+    """A forward solve with tape + the trajectories that ran out of tape steps and were integrated again with the
+    no-grad budget (`extras`: [(indices, set id, solve)]).  y / status / nsteps / nfev are the merged results."""
+
+    def __init__(self, sol, extras):
+        self.sol, self.extras = sol, extras
+        self.y, self.status, self.nsteps, self.nfev, self.tape = sol.y, sol.status, sol.nsteps, sol.nfev, sol.tape
+        self.n_retried = sum(int(i.numel()) for i, _, _ in extras)
+
+    def backward(self, gy, want_gnn=True, want_gode=False):
+        gy = gy.contiguous()
+        subs = []
+        if self.extras:
+            gy = gy.clone()
+            for idx, _, _ in self.extras:
+                subs.append(gy[idx].contiguous())
+                gy[idx] = 0                     # the truncated copy in the main launch contributes nothing
+        gx0, gnn, gode = hode.solve_bwd(self.sol, gy, want_gnn=want_gnn, want_gode=want_gode)
+        for (idx, set_id, sol2), g2 in zip(self.extras, subs):
+            g0, gn, go = hode.solve_bwd(sol2, g2, want_gnn=want_gnn, want_gode=want_gode)
+            gx0[idx] = g0
+            if gn is not None:
+                P = gn.numel()
+                gnn[P * set_id:P * (set_id + 1)] += gn
+            if go is not None:
+                gode[17 * set_id:17 * (set_id + 1)] += go
+        return gx0, gnn, gode
+
+
+def _solve_taped(x0, t, meal, tvns, gd, ode_vec, nn_flat, H, L, method, rtol, atol, n_sets, steps, tape=None):
+    """Forward solve with a tape of `steps` accepted steps per trajectory; status-1 trajectories (budget exhausted) are
+    solved again, set by set, with the inference budget and their rows replace the truncated ones.  One host
+    synchronisation (the failure count); no second launch in the common case."""
+    sol = hode.solve_fwd(x0, t, meal, tvns, gd, ode_vec, nn_flat, H, L, method=method, rtol=rtol, atol=atol, n_sets=n_sets,
+                         want_tape=tape is None, tape=tape, max_steps=steps)
+    extras = []
+    big = _eval_steps(t.shape[-1], method)
+    if big > steps:
+        bad = torch.nonzero(sol.status == 1).flatten()
+        if bad.numel():
+            per_set, P = x0.shape[0] // n_sets, nn_flat.numel() // n_sets
+            cut = lambda v, i: None if v is None else v[i].contiguous()          # noqa: E731
+            for set_id in torch.unique(bad // per_set).tolist():
+                idx = bad[(bad // per_set) == set_id]
+                s2 = hode.solve_fwd(x0[idx].contiguous(), t[idx].contiguous() if t.dim() == 2 else t, cut(meal, idx), cut(tvns, idx),
+                                    cut(gd, idx), ode_vec[17 * set_id:17 * (set_id + 1)], nn_flat[P * set_id:P * (set_id + 1)], H, L,
+                                    method=method, rtol=rtol, atol=atol, n_sets=1, want_tape=True, max_steps=big)
+                sol.y[idx], sol.status[idx], sol.nsteps[idx], sol.nfev[idx] = s2.y, s2.status, s2.nsteps, s2.nfev
+                extras.append((idx, set_id, s2))
+    return _Taped(sol, extras)
 
 
 class _SolveFn(torch.autograd.Function):
     """forward solve (K2+K3); backward = reverse-time discrete adjoint (K4)."""
 
     @staticmethod
-    def forward(ctx, x0, nn_flat, ode_vec, t, meal, tvns, gd, H, L, method, rtol, atol, n_sets, info):
+    def forward(ctx, x0, nn_flat, ode_vec, t, meal, tvns, gd, H, L, method, rtol, atol, n_sets, info, tape_steps=None):
         need_tape = any(ctx.needs_input_grad[:3])
         B, T = x0.shape[0], t.shape[-1]
-        steps = _tape_steps(T, method)
+        steps = _tape_steps(T, method, tape_steps)
         per_traj = hode.capi.tape_nbytes(1, steps, x0.element_size(), L)
         budget = _tape_budget(x0.device) if need_tape else 0
         ctx.chunked = need_tape and B * per_traj > budget
-        # same accepted-step budget on both routes, so a chunked solve returns the same trajectories bit for bit
-        sol = hode.solve_fwd(x0, t, meal, tvns, gd, ode_vec, nn_flat, H, L, method=method, rtol=rtol, atol=atol,
-                             n_sets=n_sets, want_tape=need_tape and not ctx.chunked, max_steps=steps if need_tape else None)
-        ctx.sol = sol if need_tape and not ctx.chunked else None
+        ctx.sol = None
+        if need_tape and not ctx.chunked:
+            sol = ctx.sol = _solve_taped(x0, t, meal, tvns, gd, ode_vec, nn_flat, H, L, method, rtol, atol, n_sets, steps)
+            info["n_budget_retries"] = sol.n_retried
+        else:
+            # above the tape budget: no tape now, the backward re-integrates chunk by chunk (same trajectories: a
+            # trajectory's result does not depend on its step budget unless it runs out, and then it is retried)
+            sol = hode.solve_fwd(x0, t, meal, tvns, gd, ode_vec, nn_flat, H, L, method=method, rtol=rtol, atol=atol,
+                                 n_sets=n_sets)
         if ctx.chunked:
             ctx.args = (x0, nn_flat, ode_vec, t, meal, tvns, gd, H, L, method, rtol, atol, n_sets, steps,
                         per_traj)
@@ -108,9 +181,9 @@ class _SolveFn(torch.autograd.Function):
     def backward(ctx, gy):
         need = ctx.needs_input_grad
         if not ctx.chunked:
-            gx0, gnn, gode = hode.solve_bwd(ctx.sol, gy.contiguous(), want_gnn=need[1], want_gode=need[2])
+            gx0, gnn, gode = ctx.sol.backward(gy, want_gnn=need[1], want_gode=need[2])
             ctx.sol = None
-            return (gx0 if need[0] else None, gnn, gode) + (None,) * 11
+            return (gx0 if need[0] else None, gnn, gode) + (None,) * 12
         x0, nn_flat, ode_vec, t, meal, tvns, gd, H, L, method, rtol, atol, n_sets, steps, per_traj = ctx.args
         ctx.args = None
         cap = max(1, _tape_budget(x0.device) // per_traj)      # what fits NOW (other tapes may have been freed or made)
@@ -125,17 +198,17 @@ class _SolveFn(torch.autograd.Function):
         tape = None
         cut = lambda v, lo, hi: None if v is None else v[lo:hi]          # noqa: E731  ([B,T] and [B] inputs alike)
         for lo, hi, s0, s1 in pieces:
-            sol = hode.solve_fwd(x0[lo:hi], t[lo:hi] if t.dim() == 2 else t, cut(meal, lo, hi), cut(tvns, lo, hi),
-                                 cut(gd, lo, hi), ode_vec[17 * s0:17 * s1], nn_flat[P * s0:P * s1], H, L, method=method,
-                                 rtol=rtol, atol=atol, n_sets=s1 - s0, want_tape=tape is None, tape=tape, max_steps=steps)
+            sol = _solve_taped(x0[lo:hi], t[lo:hi] if t.dim() == 2 else t, cut(meal, lo, hi), cut(tvns, lo, hi),
+                               cut(gd, lo, hi), ode_vec[17 * s0:17 * s1], nn_flat[P * s0:P * s1], H, L, method, rtol, atol,
+                               s1 - s0, steps, tape=tape)
             tape = sol.tape                                              # largest chunk first: later ones fit
-            g0, gn, go = hode.solve_bwd(sol, gy[lo:hi], want_gnn=need[1], want_gode=need[2])
+            g0, gn, go = sol.backward(gy[lo:hi], want_gnn=need[1], want_gode=need[2])
             gx0[lo:hi] = g0
             if gn is not None:
                 gnn[P * s0:P * s1] += gn
             if go is not None:
                 gode[17 * s0:17 * s1] += go
-        return (gx0 if need[0] else None, gnn, gode) + (None,) * 11
+        return (gx0 if need[0] else None, gnn, gode) + (None,) * 12
 
 
 def _allreduce_sum(tensors, group):
@@ -173,28 +246,32 @@ class _GaussLikFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x0, nn_flat, ode_vec, t, meal, tvns, gd, obs, H, L, method, rtol, atol, S, info, group=None,
-                want_y=False):
+                want_y=False, tape_steps=None):
         need = ctx.needs_input_grad
         grads = any(need[:3])
         B, T = x0.shape[0], t.shape[-1]
         P = nn_flat.numel() // S
-        steps = _tape_steps(T, method)
+        steps = _tape_steps(T, method, tape_steps)
         cap = max(1, _tape_budget(x0.device) // hode.capi.tape_nbytes(1, steps, x0.element_size(), L)) if grads else S * B
         ss = torch.zeros(1, dtype=torch.float64, device=x0.device)
         gx0 = torch.zeros_like(x0) if need[0] else None
         gnn = torch.zeros_like(nn_flat) if need[1] else None
         gode = torch.zeros_like(ode_vec) if need[2] else None
-        tape, stat, nst, nfe, ys = None, [], [], [], []
+        tape, stat, nst, nfe, ys, retried = None, [], [], [], [], 0
         for s0, s1, lo, hi in _pieces(S, B, cap):
             m = s1 - s0
             rep = lambda v: None if v is None else (v[lo:hi].repeat(m, *([1] * (v.dim() - 1))) if m > 1 else v[lo:hi])  # noqa: E731
-            sol = hode.solve_fwd(rep(x0), t if t.dim() == 1 else rep(t), rep(meal), rep(tvns), rep(gd), ode_vec[17 * s0:17 * s1],
-                                 nn_flat[P * s0:P * s1], H, L, method=method, rtol=rtol, atol=atol, n_sets=m,
-                                 want_tape=grads and tape is None, tape=tape, max_steps=steps)
-            tape = sol.tape
+            if grads:
+                sol = _solve_taped(rep(x0), t if t.dim() == 1 else rep(t), rep(meal), rep(tvns), rep(gd), ode_vec[17 * s0:17 * s1],
+                                   nn_flat[P * s0:P * s1], H, L, method, rtol, atol, m, steps, tape=tape)
+                tape = sol.tape
+                retried += sol.n_retried
+            else:
+                sol = hode.solve_fwd(rep(x0), t if t.dim() == 1 else rep(t), rep(meal), rep(tvns), rep(gd), ode_vec[17 * s0:17 * s1],
+                                     nn_flat[P * s0:P * s1], H, L, method=method, rtol=rtol, atol=atol, n_sets=m)
             _, gy = hode.mse_fwd_bwd(sol.y, rep(obs), 1.0, loss_sum=ss, want_grad=grads)
             if grads:
-                g0, gn, go = hode.solve_bwd(sol, gy, want_gnn=need[1], want_gode=need[2])
+                g0, gn, go = sol.backward(gy, want_gnn=need[1], want_gode=need[2])
                 if gx0 is not None:
                     gx0[lo:hi] += g0.view(m, hi - lo, 6).sum(0)
                 if gn is not None:
@@ -205,6 +282,7 @@ class _GaussLikFn(torch.autograd.Function):
             if want_y:
                 ys.append(sol.y)
         info["status"], info["nsteps"], info["nfev"] = torch.cat(stat), torch.cat(nst), torch.cat(nfe)
+        info["n_budget_retries"] = retried
         if group is not None:
             # patients sharded over the ranks, the SAME S draws everywhere: one all-reduce(sum) of
             # [per-set MLP grads | per-set ODE grads | sum of squares] makes value and gradient global on every rank
@@ -222,7 +300,7 @@ class _GaussLikFn(torch.autograd.Function):
         gx0, gnn, gode = ctx.grads
         ctx.grads = None
         sc = lambda v: None if v is None else (v * g.to(v.dtype))          # noqa: E731
-        return (sc(gx0), sc(gnn), sc(gode)) + (None,) * 14
+        return (sc(gx0), sc(gnn), sc(gode)) + (None,) * 15
 
 
 class HybridODENN(nn.Module):
@@ -244,6 +322,9 @@ class HybridODENN(nn.Module):
         # elbo() / loss(): compute the Gaussian (MSE) data term and its gradient in one pass over the batch -- no tape
         # kept for a later backward.  False: the solve goes through autograd like any other op (_SolveFn).
         self.fused_likelihood = True
+        # accepted-step budget per trajectory of solves that record a tape (None: T-1 + max(32, (T-1)//4)); trajectories
+        # that need more are retried with the no-grad budget, see _solve_taped
+        self.tape_steps: Optional[int] = None
         self.last_solve_info: Dict[str, torch.Tensor] = {}
         self.variational_params = None
         if use_variational:
@@ -366,7 +447,7 @@ class HybridODENN(nn.Module):
         nl = self.nn_residual
         if diff and torch.is_grad_enabled():
             y = _SolveFn.apply(x0.contiguous(), nn_flat, ode_vec, t, ins["meal"], ins["tVNS"], ins["GD"],
-                               nl.hidden_dim, nl.n_layers, method, float(rtol), float(atol), n_sets, info)
+                               nl.hidden_dim, nl.n_layers, method, float(rtol), float(atol), n_sets, info, self.tape_steps)
         else:
             with torch.no_grad():
                 sol = hode.solve_fwd(x0.contiguous(), t, ins["meal"], ins["tVNS"], ins["GD"], ode_vec.detach(),
@@ -387,6 +468,12 @@ class HybridODENN(nn.Module):
                 st = info["status"][bad].tolist()
                 for b, s in list(zip(bad.tolist(), st))[:8]:
                     logger.warning(f"ODE solver failed for batch {b}: {msgs.get(s, s)}")
+
+    def solve_failures(self) -> int:
+        """Number of trajectories of the last solve / loss / elbo that did not reach the end of their grid (their rows
+        from the failure on are zero, hybrid_ode_nn.py:243-256).  Synchronises with the device."""
+        st = self.last_solve_info.get("status")
+        return 0 if st is None else int((st != 0).sum())
 
     def forward(self, initial_state: torch.Tensor, t_span: torch.Tensor,
                 external_inputs: Optional[Dict[str, torch.Tensor]] = None, solver: str = "dopri5",
@@ -487,7 +574,7 @@ class HybridODENN(nn.Module):
             info, nl = {}, self.nn_residual
             ss = _GaussLikFn.apply(xs, nn_flat, ode_vec, tt, ins["meal"], ins["tVNS"], ins["GD"],
                                    obs.to(dev, torch.float32).contiguous(), nl.hidden_dim, nl.n_layers, method, float(rtol),
-                                   float(atol), S, info, group)
+                                   float(atol), S, info, group, False, self.tape_steps)
             self.last_solve_info = info
             self._warn_failures(info)
             return (-0.5 * ss / (noise_sigma ** 2 * S) - log_norm - kl).to(self.device)
@@ -530,7 +617,7 @@ class HybridODENN(nn.Module):
             info, nl = {}, self.nn_residual
             ss, pred = _GaussLikFn.apply(xs, nn_flat, ode_vec, tt, ins["meal"], ins["tVNS"], ins["GD"],
                                          obs.to(dev, torch.float32).contiguous(), nl.hidden_dim, nl.n_layers, hode.METHOD_DP54,
-                                         1e-6, 1e-8, 1, info, None, True)
+                                         1e-6, 1e-8, 1, info, None, True, self.tape_steps)
             self.last_solve_info = info
             self._warn_failures(info)
             data_loss = (ss / obs.numel()).float()

@@ -240,6 +240,9 @@ static const double SFX(dpA)[7][6] = {
 static const double SFX(dpE)[7] = {-71.0 / 57600, 0, 71.0 / 16695, -71.0 / 1920,
                                    17253.0 / 339200, -22.0 / 525, 1.0 / 40};
 
+#ifndef HODE_SEG_CLOSED
+#define HODE_SEG_CLOSED (1 << 30)   /* bit 30 of tape seg: the step ended exactly on the grid point closing its interval */
+#endif
 typedef struct { REAL t, h, y[6]; int seg; } SFX(tape_t);
 
 /*
@@ -280,6 +283,7 @@ int SFX(hode_oracle_solve)(int B, int T, const REAL *x0, const REAL *tg, int t_b
             if (!(len > 0)) { for (int i = 0; i < 6; ++i) yb[6 * (k + 1) + i] = yc[i]; continue; }
             REAL tc = s.t0, mm, vv, dd;
             if (method == 1) {                       /* classic RK4, one step per interval */
+                if (ns >= max_steps) { st = 1; break; }   /* budget < T-1: report, rows from here on stay zero */
                 REAL k1[6], k2[6], k3[6], k4[6], yt[6];
                 REAL hh = len;
                 SFX(seg_eval)(&s, tc, &mm, &vv, &dd);
@@ -294,7 +298,7 @@ int SFX(hode_oracle_solve)(int B, int T, const REAL *x0, const REAL *tg, int t_b
                 SFX(rhs_one)(&m, ode, s.t1, yt, mm, vv, dd, s.use_gd, k4, act);
                 if (tape && ns < max_steps) {
                     SFX(tape_t) *e = tape + (size_t)b * max_steps + ns;
-                    e->t = tc; e->h = hh; e->seg = k; for (int i = 0; i < 6; ++i) e->y[i] = yc[i];
+                    e->t = tc; e->h = hh; e->seg = k | HODE_SEG_CLOSED; for (int i = 0; i < 6; ++i) e->y[i] = yc[i];
                 }
                 for (int i = 0; i < 6; ++i)
                     yc[i] += hh / (REAL)6 * (k1[i] + (REAL)2 * k2[i] + (REAL)2 * k3[i] + k4[i]);
@@ -374,7 +378,7 @@ int SFX(hode_oracle_solve)(int B, int T, const REAL *x0, const REAL *tg, int t_b
                             if (rejected) fac = fmin(1.0, fac);
                             if (tape) {
                                 SFX(tape_t) *e = tape + (size_t)b * max_steps + ns;
-                                e->t = tc; e->h = h; e->seg = k; for (int i = 0; i < 6; ++i) e->y[i] = yc[i];
+                                e->t = tc; e->h = h; e->seg = k | (clipped ? HODE_SEG_CLOSED : 0); for (int i = 0; i < 6; ++i) e->y[i] = yc[i];
                             }
                             /* a clipped step must not shrink the carried proposal */
                             REAL hn = h * (REAL)fac;
@@ -431,11 +435,21 @@ int SFX(hode_oracle_solve_bwd)(int B, int T, const REAL *tg, int t_batched, cons
         for (int i = 0; i < 6; ++i) lam[i] = 0;
         for (int st = n - 1; st >= 0; --st) {
             const SFX(tape_t) *e = tape + (size_t)b * max_steps + st;
-            int k = e->seg;
+            int k = e->seg & (HODE_SEG_CLOSED - 1);
             /* if this is the last step of segment k, y_{n+1} is grid row k+1 (and any following
-             * zero-length rows): inject their dLoss/dy.  A failed trajectory's unfinished last
-             * segment was never written to y, so it injects nothing. */
-            int knext = (st == n - 1) ? (ok ? T - 1 : k) : (e + 1)->seg;
+             * zero-length rows): inject their dLoss/dy.  The last step of a FAILED trajectory: if it closed
+             * its segment, row k+1 and the zero-length copies behind it were still written (up to the
+             * segment that failed); if it did not, nothing after row k was. */
+            int knext;
+            if (st < n - 1) knext = (e + 1)->seg & (HODE_SEG_CLOSED - 1);
+            else if (ok) knext = T - 1;
+            else {
+                knext = k;
+                if (e->seg & HODE_SEG_CLOSED) {
+                    knext = k + 1;
+                    while (knext + 1 < T && !(tb[knext + 1] > tb[knext])) ++knext;
+                }
+            }
             for (int r = k + 1; r <= knext; ++r)
                 for (int i = 0; i < 6; ++i) lam[i] += gy[((size_t)b * T + r) * 6 + i];
             SFX(seg_t) s;
@@ -487,8 +501,13 @@ int SFX(hode_oracle_solve_bwd)(int B, int T, const REAL *tg, int t_batched, cons
             }
             for (int i = 0; i < 6; ++i) lam[i] = newlam[i];
         }
-        /* row 0 */
-        for (int i = 0; i < 6; ++i) gx0[6 * b + i] = lam[i] + gy[((size_t)b * T) * 6 + i];
+        /* row 0 and the rows that are copies of it: the grid may start with repeated times; kf = first segment of
+         * positive length (= segment of step 0; = the segment a trajectory without any accepted step failed in) */
+        int kf = 0;
+        while (kf + 1 < T && !(tb[kf + 1] > tb[kf])) ++kf;
+        for (int r = 0; r <= kf; ++r)
+            for (int i = 0; i < 6; ++i) lam[i] += gy[((size_t)b * T + r) * 6 + i];
+        for (int i = 0; i < 6; ++i) gx0[6 * b + i] = lam[i];
     }
     if (gnn) for (int i = 0; i < P; ++i) gnn[i] = (REAL)an[i];
     if (gode) for (int i = 0; i < 17; ++i) gode[i] = (REAL)ao[i];

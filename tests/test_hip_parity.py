@@ -324,6 +324,17 @@ def test_adam_step_vs_torch(hode):
     hode.adam_step(p2, gr * 8, m2, v2, 1e-3, step=1, max_norm=5.0, grad_scale=0.125)
     hode.adam_step(p3, gr, m3, v3, 1e-3, step=1, max_norm=5.0)
     assert float((p2 - p3).abs().max()) < 1e-6
+    # with clipping ACTIVE the update is bit-reproducible: the norm is reduced in a fixed order (no atomics), so every
+    # data-parallel rank applies the same clip coefficient to the same all-reduced gradient
+    big = torch.randn(n, device="cuda") * 50
+    outs = []
+    for _ in range(4):
+        q, mq, vq = p0.clone(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+        hode.adam_step(q, big, mq, vq, 1e-3, step=1, max_norm=5.0)
+        hode.adam_step(q, big * 0.5, mq, vq, 1e-3, step=2, max_norm=5.0)
+        outs.append((q, mq, vq))
+    for q, mq, vq in outs[1:]:
+        assert torch.equal(q, outs[0][0]) and torch.equal(mq, outs[0][1]) and torch.equal(vq, outs[0][2])
 
 
 def test_mse_fwd_bwd(hode):
@@ -405,6 +416,31 @@ def test_empty_batch_and_repeated_times(hode, g0):
     assert np.array_equal(y[:, 1], y[:, 2]) and np.array_equal(y[:, 3], y[:, 5]) and rel(y, ref.y) < 1e-9
     gx0, gnn, _ = hode.solve_bwd(s, dev(c, dt))
     assert relnorm(gx0.cpu().numpy(), rx) < 1e-8 and relnorm(gnn.cpu().numpy(), rnn) < 1e-8
+    # the grid STARTS with repeated times (rows 1..k are copies of x0: their cotangents belong to gx0); every interval
+    # of zero length (no step at all); a trajectory whose step budget ends right after a step that closed its interval
+    # (that row and the zero-length copies behind it were still written).  RK4 and DP5(4).
+    for t, method, max_steps in ((np.array([0.0, 0.0, 0.0, 0.1, 0.2, 0.2, 0.35]), O.METHOD_DP54, None),
+                                 (np.array([0.0, 0.0, 0.0, 0.1, 0.2, 0.2, 0.35]), O.METHOD_RK4, None),
+                                 (np.zeros(4), O.METHOD_DP54, None),
+                                 (np.array([0.0, 0.0, 0.1, 0.2, 0.2, 0.2, 0.3, 0.4]), O.METHOD_RK4, 2)):
+        T = len(t)
+        meal = np.random.default_rng(4).random((2, T))
+        c = np.random.default_rng(5).standard_normal((2, T, 6))
+        ref = O.solve(x0, t, meal, None, None, g0["ode"], g0["nn"], 64, 4, method=method, rtol=1e-8, atol=1e-10, dtype=np.float64,
+                      want_tape=True, max_steps=max_steps)
+        rx, rnn, _ = O.solve_bwd(ref, c)
+        s = hode.solve_fwd(dev(x0, dt), dev(t, dt), dev(meal, dt), None, None, dev(g0["ode"], dt), dev(g0["nn"], dt), 64, 4,
+                           method=method, rtol=1e-8, atol=1e-10, want_tape=True, max_steps=max_steps)
+        assert np.array_equal(s.status.cpu().numpy(), ref.status) and np.array_equal(s.nsteps.cpu().numpy(), ref.nsteps)
+        assert rel(s.y.cpu().numpy(), ref.y) < 1e-9
+        gx0, gnn, _ = hode.solve_bwd(s, dev(c, dt))
+        assert relnorm(gx0.cpu().numpy(), rx) < 1e-8, (t, method)
+        if np.abs(rnn).max() > 0:
+            assert relnorm(gnn.cpu().numpy(), rnn) < 1e-8, (t, method)
+        else:
+            assert float(gnn.abs().max()) == 0
+        if max_steps is not None:
+            assert (ref.status == 1).all() and (ref.y[:, 6:] == 0).all()
 
 
 def test_constant_inputs_and_gd_through_solve(hode, golden_dir, g0):

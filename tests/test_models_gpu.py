@@ -208,6 +208,55 @@ def test_adjoint_gradient_through_class(M, golden_dir):
     assert relnorm(grads, rnn) < 1e-4
 
 
+def test_trajectories_that_outrun_the_tape_budget_are_retried_not_lost(M, golden_dir):
+    """A solve under autograd records a tape with a tight accepted-step budget (T-1 + margin).  A trajectory that needs
+    more steps must not turn into zero rows without a gradient: it is integrated again with the no-grad
+    budget, so values and status equal the no-grad solve and the gradient is the adjoint of the full trajectory."""
+    g = np.load(os.path.join(golden_dir, "g4_t61_pulses.npz"))
+    w = np.load(os.path.join(golden_dir, "g0_weights_h64_l4.npz"))
+    sel = np.arange(0, 61, 6)                                  # 11 grid points over 5 h: ~10 steps per interval at 1e-9
+    x0, t, meal, tv = g["x0"][:5], g["t"][sel], g["meal"][:5, sel], g["tvns"][:5, sel]
+    u = {"meal": torch.tensor(meal).cuda(), "tVNS": torch.tensor(tv).cuda()}
+    for fused in (False, True):
+        m = load_model(M, golden_dir, "cuda")
+        m.fused_likelihood = fused
+        m.tape_steps = 14                                      # 10 intervals: the budget covers four spare steps
+        with torch.no_grad():
+            y0 = m.forward(torch.tensor(x0).cuda(), torch.tensor(t).cuda(), u, rtol=1e-9, atol=1e-11)
+        n_need = m.last_solve_info["nsteps"].clone()
+        assert m.solve_failures() == 0 and int(n_need.min()) > 14
+        obs = y0 + 0.05 * torch.randn(y0.shape, device="cuda", generator=torch.Generator("cuda").manual_seed(1))
+        if fused:
+            e = M.HybridODENN(use_variational=True, device="cuda")      # elbo() is the fused route with free tolerances
+            e.tape_steps = 14
+            with torch.no_grad():
+                for (n1, p1) in m.nn_residual.named_parameters():
+                    e.variational_params.means["nn_" + n1.replace(".", "_")].copy_(p1)
+                for n1, p1 in e.variational_params.log_stds.items():
+                    p1.fill_(-20.0)                                       # draws == means to fp32 precision
+                for n1 in ("a_GI", "k_I", "rho", "E_max", "EC_50", "V_max", "K_m", "k_L"):
+                    e.variational_params.means["ode_" + n1].copy_(getattr(e.ode_core, n1))
+            val = e.elbo({"initial_state": torch.tensor(x0).cuda(), "observations": obs, "time_points": torch.tensor(t).cuda(),
+                          "external_inputs": u}, n_samples=2, noise_sigma=1.0, rtol=1e-9, atol=1e-11)
+            val.backward()
+            assert e.solve_failures() == 0 and e.last_solve_info["n_budget_retries"] == 10
+            assert torch.equal(e.last_solve_info["nsteps"][:5], n_need)
+            gr = torch.cat([e.variational_params.means["nn_" + n1.replace(".", "_")].grad.reshape(-1)
+                            for n1, _ in m.nn_residual.named_parameters()]).cpu().numpy()
+            scale = -0.5                                                # d elbo = -0.5 d(sum of squares) / (sigma^2) averaged over S
+        else:
+            y = m.forward(torch.tensor(x0).cuda(), torch.tensor(t).cuda(), u, rtol=1e-9, atol=1e-11)
+            assert y.requires_grad and torch.equal(y.detach(), y0)      # same bits as the no-grad solve
+            assert m.solve_failures() == 0 and m.last_solve_info["n_budget_retries"] == 5
+            ((y - obs) ** 2).sum().backward()
+            gr = torch.cat([p.grad.reshape(-1) for p in m.nn_residual.parameters()]).cpu().numpy()
+            scale = 1.0
+        ref = O.solve(x0, t, meal, tv, None, w["ode"], w["nn_flat"], 64, 4, rtol=1e-11, atol=1e-13, dtype=np.float64, want_tape=True)
+        gy = 2.0 * (y0.cpu().numpy().astype(np.float64) - obs.cpu().numpy().astype(np.float64))
+        _, rnn, _ = O.solve_bwd(ref, gy)
+        assert relnorm(gr, scale * rnn) < 2e-4, fused
+
+
 def test_validation_under_no_grad_and_ablations(M):
     """reference tests/test_training.py:187-294: validate() runs loss under no_grad; ablation modes."""
     torch.manual_seed(0)

@@ -230,3 +230,38 @@ def test_failed_trajectory_reports_status_not_exception(g0):
     s = O.solve(x0, t, None, None, None, g0["ode"], g0["nn"], 64, 4, max_steps=10, dtype=np.float32)
     assert s.status[0] == 1 and s.nsteps[0] == 10
     assert np.all(s.y[0, 11:] == 0) and np.all(s.y[0, :10, 0] != 0)
+
+
+def test_adjoint_rows_that_copy_x0_and_rows_of_a_failed_trajectory(g0):
+    """Edge cases of the cotangent injection, against central differences of the oracle forward (RK4: the step sequence
+    cannot move).  (i) the grid STARTS with repeated times: rows 1..k are copies of x0 and their cotangents belong to
+    gx0; (ii) every interval has zero length (no step at all); (iii) a trajectory that runs out of steps right after a
+    step that closed its interval: that interval's end row (and the zero-length copies behind it) were still written."""
+    rng = np.random.default_rng(5)
+    x0 = np.array([[5, 60, 80, 10, 0, 1.0], [6, 50, 70, 12, 0.1, 0.9]])
+    nn, ode = g0["nn"].astype(np.float64), g0["ode"].astype(np.float64)
+
+    def run(x, t, c, max_steps=None):
+        s = O.solve(x, t, meal, None, None, ode, nn, 64, 4, method=O.METHOD_RK4, dtype=np.float64, want_tape=True,
+                    max_steps=max_steps)
+        return float((s.y * c).sum()), s
+
+    for t, max_steps in ((np.array([0.0, 0.0, 0.0, 0.1, 0.2, 0.2, 0.35]), None),      # (i)
+                         (np.zeros(4), None),                                         # (ii)
+                         (np.array([0.0, 0.0, 0.1, 0.2, 0.2, 0.2, 0.3, 0.4]), 2)):    # (iii): budget ends after interval 2
+        T = len(t)
+        meal = rng.random((2, T))
+        c = rng.standard_normal((2, T, 6))
+        L, s = run(x0, t, c, max_steps)
+        if max_steps is not None:
+            assert (s.status == 1).all() and (s.nsteps == 2).all()
+            assert (s.y[:, 6:] == 0).all() and (s.y[:, 5] != 0).any()      # rows 3 (closing row), 4, 5 (copies) written
+        gx0, gnn, _ = O.solve_bwd(s, c)
+        for b in range(2):
+            for i in range(6):
+                e = 1e-6 * max(1.0, abs(x0[b, i]))
+                xp, xm = x0.copy(), x0.copy()
+                xp[b, i] += e
+                xm[b, i] -= e
+                fd = (run(xp, t, c, max_steps)[0] - run(xm, t, c, max_steps)[0]) / (2 * e)
+                assert abs(fd - gx0[b, i]) <= 2e-6 * max(1.0, abs(fd)), (t, b, i, fd, gx0[b, i])
