@@ -41,7 +41,60 @@ FLOP_PER_STEP_ALGEBRA = 400                                   # stage sums, erro
 BYTES_FWD_PER_TRAJ = 24 + 964 + 964 + 241 * 6 * 4            # x0 + meal row + tVNS row + y  = 7 736 B
 BYTES_TRAIN_PER_TRAJ = 21_300
 PEAK_FP32_TFLOPS = 157.3                                      # MI355X_MICROARCH.md: fp32 vector == f32-MFMA dense peak
+PEAK_FP64_TFLOPS = 78.6                                       # fp64 vector = half the fp32 vector rate (MI355X data sheet; the guide lists fp32 only)
 PEAK_HBM_GBS = 8000.0
+# adjoint, per stage of an accepted step: outer products dW += delta (x) h and the W^T delta products = 2x the MACs of the
+# forward RHS (nothing is recomputed: activations come from the stage tape), plus the mechanistic J^T and edge layers
+FLOP_PER_ADJ_STAGE = 2 * FLOP_PER_RHS
+# stage tape record = (L+1) rows x 64 lanes x 4 B per stage; tape entry 32 B + 4 B interval index per step
+STAGE_REC_BYTES = (L + 1) * 64 * 4
+# 4GI generator (K7): per RHS ~60 add/mul/div + 3 pow (exp(p log x), ~40 flop each); DP5(4) stage algebra of 8 states
+FLOP_PER_4GI_RHS = 60 + 3 * 40
+FLOP_PER_4GI_STEP = 6 * FLOP_PER_4GI_RHS + 8 * 2 * (21 + 7) + 40
+
+
+def kernel_source_sha():
+    """sha256 over the kernel sources: profiles/pmc_traffic.json carries the value it was measured at, so a PMC reading
+    taken on other kernels is never reported as this run's traffic."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "hybrid-ode-for-glp-1-and-glucose_amd", "csrc", "*.h*"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def measured_traffic(key):
+    """HBM bytes per launch from the committed PMC passes (tools/profile_gpu.sh -> tools/summarize_profile.py), or None when
+    the kernels have changed since (or the file is missing)."""
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        d = json.load(open(pmc))
+    except Exception:
+        return None, "no PMC file"
+    if d.get("kernel_source_sha") != kernel_source_sha():
+        return None, f"stale: PMC passes were taken at kernel sources {d.get('kernel_source_sha')}, this run is {kernel_source_sha()}"
+    return d.get(key), d.get("source")
+
+
+def ensure_built():
+    """Fresh checkout (built artefacts are git-ignored): build BEFORE any GPU / collective call.  Every rank takes the
+    same path: an exclusive file lock, then `make` (a no-op when up to date; the Makefile links to a temporary name and
+    renames it, so no rank can dlopen a half-written library)."""
+    import fcntl
+    import subprocess
+    pkg = os.path.join(ROOT, "hybrid-ode-for-glp-1-and-glucose_amd")
+    with open(os.path.join(pkg, "csrc", ".build.lock"), "w") as lk:
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        try:
+            if not os.path.exists(os.path.join(pkg, "hode", "libhode.so")):
+                subprocess.run(["make", "-C", os.path.join(pkg, "csrc"), "-j4", "ARCH=gfx950"], check=True,
+                               stdout=subprocess.DEVNULL)
+            if not os.path.exists(os.path.join(ROOT, "oracle", "_build", "libhode_oracle.so")):
+                subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "-s"], check=True, stdout=subprocess.DEVNULL)
+        finally:
+            fcntl.flock(lk, fcntl.LOCK_UN)
 
 
 def synth_weights(seed=0):
@@ -73,29 +126,61 @@ def synth_cohort(B, seed):
     return x0, t, meal, tvns
 
 
-def cpu_baseline(sample, seconds_budget=20.0):
-    """Oracle (C port of the same grid-broken DP5(4), oracle/hode_oracle.c) on the host cores."""
+def cpu_baseline(c_sample, ref_sample=256, ref_one_thread=48):
+    """The reference's CPU path beside the GPU number, on this box's host cores:
+      * reference-style (the headline of this object): per-patient scipy.integrate.solve_ivp(method='RK45', 1e-6 / 1e-8)
+        loop with an fp32 torch-CPU RHS -- what reference models/hybrid_ode_nn.py:184-256 does, restated over this repo's own
+        ODECore / NNResidual modules (oracle/reference_style.py; the reference's Python cannot travel to the GPU box).
+        One thread, and one worker process per core;
+      * c_port: the C oracle (same grid-broken DP5(4) as the kernel, oracle/hode_oracle.c), one thread per core."""
     from oracle import oracle as O
+    from oracle import reference_style as RS
     O.lib()
     ncores = max(1, min(os.cpu_count() or 1, 16))     # the GPU box gives one GPU a 16-core share
-    x0, t, meal, tvns = (v.numpy() for v in synth_cohort(sample, 12345))
+    x0, t, meal, tvns = (v.numpy() for v in synth_cohort(max(c_sample, ref_sample), 12345))
     nn, ode = synth_weights().numpy(), ODE_DEFAULT.numpy()
+
+    # reference-style, one thread
+    torch_threads = torch.get_num_threads()
+    torch.set_num_threads(1)
+    n1 = min(ref_one_thread, ref_sample)
+    RS.solve(x0[:2], t, {"meal": meal[:2], "tVNS": tvns[:2]}, nn, ode, H, L, solver="rk45")          # warm-up
+    cnt = {}
+    t0 = time.perf_counter()
+    y_ref = RS.solve(x0[:n1], t, {"meal": meal[:n1], "tVNS": tvns[:n1]}, nn, ode, H, L, solver="rk45", count=cnt)
+    dt1 = time.perf_counter() - t0
+    torch.set_num_threads(torch_threads)
+    # reference-style, all cores (worker start-up and imports are outside the timed region)
+    _, nfev_all, procs, dt_all = RS.solve_all_cores(x0[:ref_sample], t, {"meal": meal[:ref_sample], "tVNS": tvns[:ref_sample]}, nn, ode,
+                                                    H, L, solver="rk45", procs=ncores, timed=True)
 
     def work(sl):
         s = O.solve(x0[sl], t, meal[sl], tvns[sl], None, ode, nn, H, L, rtol=1e-6, atol=1e-8, dtype=np.float32)
         return int(s.nsteps.sum())
 
-    chunks = [slice(i, min(i + 16, sample)) for i in range(0, sample, 16)]
+    chunks = [slice(i, min(i + 16, c_sample)) for i in range(0, c_sample, 16)]
     work(slice(0, 4))
     t0 = time.perf_counter()
     with ThreadPoolExecutor(ncores) as ex:        # ctypes releases the GIL: real threads
         list(ex.map(work, chunks))
-    dt = time.perf_counter() - t0
-    out = {"value": sample / dt, "unit": "patient-trajectories/s", "cores": ncores, "kind": "port",
-           "sample": f"{sample} trajectories of the same synthetic cohort (T=241, fp32, rtol 1e-6/atol 1e-8), "
-                     f"C oracle, {ncores} threads, {dt:.1f} s wall",
-           "per_core": sample / dt / ncores}
+    dtc = time.perf_counter() - t0
+    out = {"value": ref_sample / dt_all, "unit": "patient-trajectories/s", "cores": procs, "kind": "port",
+           "path": "reference-style: per-patient scipy solve_ivp(RK45, rtol 1e-6, atol 1e-8) loop, fp32 torch-CPU RHS "
+                   "(reference models/hybrid_ode_nn.py:184-256 restated in oracle/reference_style.py)",
+           "sample": f"{ref_sample} trajectories of the same synthetic cohort (T=241) over {procs} worker processes, {dt_all:.1f} s wall",
+           "per_core": ref_sample / dt_all / procs,
+           "one_thread": {"value": n1 / dt1, "unit": "patient-trajectories/s", "cores": 1,
+                          "sample": f"{n1} trajectories, {dt1:.1f} s", "rhs_calls_per_trajectory": cnt["nfev"] / n1},
+           "c_port": {"value": c_sample / dtc, "unit": "patient-trajectories/s", "cores": ncores, "kind": "port",
+                      "per_core": c_sample / dtc / ncores,
+                      "sample": f"{c_sample} trajectories, C oracle (the kernel's own grid-broken DP5(4), fp32), {ncores} threads, {dtc:.1f} s wall"}}
     out["parity_check"] = parity_check(O, x0[:16], t, meal[:16], tvns[:16], nn, ode)
+    # what the reference itself would have returned for the first trajectories (default tolerances: ~1e-2 with meals, SURVEY F6)
+    import hode
+    dev = torch.device("cuda", torch.cuda.current_device())
+    f32 = lambda a: torch.as_tensor(a, dtype=torch.float32, device=dev)          # noqa: E731
+    yk = hode.solve_fwd(f32(x0[:n1]), f32(t), f32(meal[:n1]), f32(tvns[:n1]), None, f32(ode), f32(nn), H, L).y.cpu().numpy()
+    out["parity_check"]["vs_reference_style_default_tolerances"] = float(np.max(np.abs(yk - y_ref) / (np.abs(y_ref) + 1e-3)))
     return out
 
 
@@ -184,18 +269,29 @@ def data_side(dev, B, cpu=True):
     alg = table.numel() * 8 + row0.numel() * S * 9 * 4          # table read once + fp32 batches written once
     out = {"workload": f"{B} subjects x {T} grid points (5 h at 5 min), T2DM, 2 meals, fp64 DP5(4) rtol 1e-10; windows {S}/{stride}",
            "generate": {"ms": ms_gen, "subjects_per_s": B / ms_gen * 1e3, "failed": int((status != 0).sum()),
-                        "kernel": "fourgi_generate_kernel (one subject per lane)", "bound": "fp64 VALU latency (3 pow per RHS), 1 wave/SIMD"},
+                        "kernel": "fourgi_generate_kernel (one subject per lane)", "bound": "fp64 VALU latency (3 pow per RHS), 1 wave/SIMD",
+                        "algorithmic_bytes": B * T * (72 + 40)},
            "windows": {"ms": ms_win, "windows": int(row0.numel()), "algorithmic_bytes": alg,
                        "roofline": {"bound": "hbm", "achieved": alg / ms_win / 1e6, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                     "frac": alg / ms_win / 1e6 / PEAK_HBM_GBS}}}
+    gen = out["generate"]
+    traffic, src = measured_traffic("fourgi_generate_hbm_bytes_per_launch")
+    gen["roofline_hbm"] = {"bound": "hbm", "achieved": gen["algorithmic_bytes"] / ms_gen / 1e6, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                           "frac": gen["algorithmic_bytes"] / ms_gen / 1e6 / PEAK_HBM_GBS, "traffic": traffic, "traffic_source": src}
     if cpu:
         from oracle import fourgi
         n = 512
         t0 = time.perf_counter()
-        fourgi.simulate(bsl[:n].cpu().numpy(), T, 5.0, [0.5, 2.5], [75.0, 50.0])
+        _, _, steps = fourgi.simulate(bsl[:n].cpu().numpy(), T, 5.0, [0.5, 2.5], [75.0, 50.0])
         dt = time.perf_counter() - t0
-        out["generate"]["cpu_baseline"] = {"value": n / dt, "unit": "subjects/s", "cores": 1, "kind": "port",
-                                           "sample": f"{n} subjects of the same cohort, C oracle (DP5(4) at the same tolerances)"}
+        gen["cpu_baseline"] = {"value": n / dt, "unit": "subjects/s", "cores": 1, "kind": "port",
+                               "sample": f"{n} subjects of the same cohort, C oracle (DP5(4) at the same tolerances)"}
+        # fp64 vector roofline of the generator: accepted steps per subject from the oracle (same algorithm) on that sample
+        flops = B * (steps / n) * FLOP_PER_4GI_STEP
+        gen["roofline"] = {"bound": "valu_fp64", "achieved": flops / (ms_gen * 1e-3) / 1e12, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
+                           "frac": flops / (ms_gen * 1e-3) / 1e12 / PEAK_FP64_TFLOPS, "accepted_steps_per_subject": steps / n,
+                           "algorithmic_flops_per_step": FLOP_PER_4GI_STEP,
+                           "note": "one subject per lane, 1 wave/SIMD (56 live fp64 stage derivatives): latency-bound, far from either roof"}
     return out
 
 
@@ -206,7 +302,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--patients-per-gpu", type=int, default=4096)
     ap.add_argument("--train-steps", type=int, default=5)
-    ap.add_argument("--cpu-sample", type=int, default=65536)
+    ap.add_argument("--cpu-sample", type=int, default=32768, help="trajectories of the C-oracle leg of cpu_baseline")
+    ap.add_argument("--ref-sample", type=int, default=256, help="trajectories of the reference-style (solve_ivp loop) leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true")
     ap.add_argument("--no-data-side", action="store_true")
@@ -223,6 +320,7 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.gpus > 1 and world == 1:
         raise SystemExit("for --gpus N > 1 launch with torch.distributed.run (one rank per GPU)")
+    ensure_built()                                   # before any GPU / collective call; every rank takes the same path
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     ndev = torch.cuda.device_count()
@@ -236,13 +334,6 @@ def main():
         else:
             dist.init_process_group("gloo")                     # rehearsal only (collectives staged through the host)
 
-    if not os.path.exists(os.path.join(ROOT, "hybrid-ode-for-glp-1-and-glucose_amd", "hode", "libhode.so")):
-        # fresh checkout (built artefacts are git-ignored): rank 0 of the node builds, the others wait
-        if local_rank == 0:
-            import __graft_entry__
-            __graft_entry__.build()
-        if world > 1:
-            dist.barrier()
     import hode
     hode.load()
     B = args.patients_per_gpu
@@ -333,7 +424,43 @@ def main():
         tw = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
         allreduce_max(tw)
         losses.append(float(loss))
-        train = {"metric": "patient-trajectories/s (fwd + adjoint + all-reduce + fused Adam)",
+        # the two kernels of the step, timed one by one with HIP events on the launch stream (rocprofv3 agrees: profiles/)
+        def kernel_ms(fn, reps=3):
+            fn()
+            torch.cuda.synchronize()
+            a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a0.record()
+            for _ in range(reps):
+                r = fn()
+            a1.record()
+            torch.cuda.synchronize()
+            return a0.elapsed_time(a1) / reps, r
+        ms_ft, solt = kernel_ms(lambda: hode.solve_fwd(x0, t, meal, tvns, None, ode, state.p, H, L, want_tape=True, tape=state.tape))
+        gy_probe = torch.randn(B, T, 6, device=dev, generator=torch.Generator(dev).manual_seed(3)) / (B * T * 6)
+        ms_adj, _ = kernel_ms(lambda: hode.solve_bwd(solt, gy_probe))
+        st_steps = float(solt.nsteps.double().sum())
+        st_nfev = float(solt.nfev.double().sum())
+        adj_flops = st_steps * 6 * FLOP_PER_ADJ_STAGE
+        tape_bytes = st_steps * (6 * STAGE_REC_BYTES + 36) + B * (T * 6 * 4 + 2 * T * 4)      # stage tape + entries + dLoss/dy + inputs
+        fwt_flops = st_nfev * FLOP_PER_RHS + st_steps * FLOP_PER_STEP_ALGEBRA
+        fwt_bytes = st_steps * (6 * STAGE_REC_BYTES + 36) + B * BYTES_FWD_PER_TRAJ
+        tr_adj, src_adj = measured_traffic("solve_bwd_hbm_bytes_per_launch")
+        tr_fwt, _ = measured_traffic("solve_fwd_tape_hbm_bytes_per_launch")
+        roof = {"adjoint": {"kernel": "solve_bwd_kernel<float,4>", "kernel_ms": ms_adj, "bound": "valu_fp32",
+                            "achieved": adj_flops / (ms_adj * 1e-3) / 1e12, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                            "frac": adj_flops / (ms_adj * 1e-3) / 1e12 / PEAK_FP32_TFLOPS, "algorithmic_flops_per_launch": adj_flops,
+                            "flops_model": "2 x forward RHS flops per stage (dW outer products + W^T delta products; no recompute)",
+                            "traffic": tr_adj, "traffic_source": src_adj,
+                            "hbm": {"achieved": tape_bytes / (ms_adj * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                    "frac": tape_bytes / (ms_adj * 1e-3) / 1e9 / PEAK_HBM_GBS, "algorithmic_bytes_per_launch": tape_bytes,
+                                    "note": "bytes the adjoint must stream back: stage tape (activations + stage states) + step entries + dLoss/dy"}},
+                "forward_with_tape": {"kernel": "solve_fwd_kernel<float,4,DP54,TAPE>", "kernel_ms": ms_ft, "bound": "valu_fp32",
+                                      "achieved": fwt_flops / (ms_ft * 1e-3) / 1e12, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                                      "frac": fwt_flops / (ms_ft * 1e-3) / 1e12 / PEAK_FP32_TFLOPS, "traffic": tr_fwt,
+                                      "hbm": {"achieved": fwt_bytes / (ms_ft * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                              "frac": fwt_bytes / (ms_ft * 1e-3) / 1e9 / PEAK_HBM_GBS, "algorithmic_bytes_per_launch": fwt_bytes}}}
+        train = {"roofline": roof,
+                 "metric": "patient-trajectories/s (fwd + adjoint + all-reduce + fused Adam)",
                  "value": world * B * args.train_steps / float(tw), "ms_per_step": float(tw) / args.train_steps * 1e3,
                  "steps": args.train_steps, "loss_first_last": [losses[0], losses[-1]],
                  "collective": "1 x all_reduce(sum) of 13 529 fp32 (54 KB) per step" if world > 1 else "none (1 rank)"}
@@ -342,13 +469,7 @@ def main():
         flops = nfev * FLOP_PER_RHS + nsteps * FLOP_PER_STEP_ALGEBRA
         tflops = flops / (kern_ms * 1e-3) / 1e12
         gbs = B * BYTES_FWD_PER_TRAJ / (kern_ms * 1e-3) / 1e9
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
-            try:
-                traffic = json.load(open(pmc)).get("solve_fwd_hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        traffic, traffic_src = measured_traffic("solve_fwd_hbm_bytes_per_launch")
         out = {
             "metric": "patient-trajectories/s (6-state, 240-step dopri5)", "value": value,
             "unit": "patient-trajectories/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -358,10 +479,10 @@ def main():
                                    "(rtol 1e-6, atol 1e-8), ODE + 4x64 MLP residual, fp32, forward solve, T=241",
                        "patients_per_gpu": B, "grid_points": T, "parallelism": f"patients sharded x{world}, no data-path collective",
                        "trajectories_ok": ok, "mean_steps": nsteps / B, "mean_nfev": nfev / B},
-            "roofline": {"bound": "mfma", "bound_detail": "fp32 vector FMA (MFMA deliberately unused, north_star); the f32 "
-                         "MFMA dense peak equals the fp32 vector peak, 157.3 TFLOP/s",
+            "roofline": {"bound": "valu_fp32", "bound_detail": "fp32 vector FMA issue (MFMA deliberately unused, north_star); peak = "
+                         "fp32 vector peak 157.3 TFLOP/s (= the f32 MFMA dense peak)",
                          "achieved": tflops, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": tflops / PEAK_FP32_TFLOPS,
-                         "traffic": traffic, "kernel": "solve_fwd_kernel<float,4,DP54>", "kernel_ms": kern_ms,
+                         "traffic": traffic, "traffic_source": traffic_src, "kernel": "solve_fwd_kernel<float,4,DP54>", "kernel_ms": kern_ms,
                          "algorithmic_flops_per_launch": flops,
                          "hbm": {"achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
                                  "algorithmic_bytes_per_launch": B * BYTES_FWD_PER_TRAJ}},
@@ -375,7 +496,7 @@ def main():
         if world == 1 and not args.no_data_side:
             out["data_side"] = data_side(dev, args.cohort, cpu=not args.no_cpu_baseline)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_sample)
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.ref_sample)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

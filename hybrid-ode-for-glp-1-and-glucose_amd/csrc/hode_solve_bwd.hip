@@ -133,7 +133,7 @@ __global__ __launch_bounds__(WTREG ? 256 : 64 * kBwdWaves, (sizeof(R) == 4 && !W
         const int *__restrict__ tseg = a.tape_seg + (size_t)b * a.max_steps;
         const R *__restrict__ stg = a.tape_stage + (size_t)b * a.max_steps * 6 * kSlot;
         const R *__restrict__ gyb = a.gy + (size_t)b * T * 6;
-        const int n = a.nsteps[b];
+        const int n = a.nsteps[b] < a.max_steps ? a.nsteps[b] : a.max_steps;     // never walk past the tape, whatever the caller passes
         const bool ok = a.status[b] == HODE_ST_OK;
         R lam = R(0);                              // cotangent of the state, replicated per 8-lane group
         int knext = T - 1;                         // grid interval of the step after the current one

@@ -104,7 +104,13 @@ class _Taped:
 
     def __init__(self, sol, extras):
         self.sol, self.extras = sol, extras
-        self.y, self.status, self.nsteps, self.nfev, self.tape = sol.y, sol.status, sol.nsteps, sol.nfev, sol.tape
+        self.y, self.tape = sol.y, sol.tape
+        self.status, self.nsteps, self.nfev = sol.status, sol.nsteps, sol.nfev
+        if extras:
+            # merged bookkeeping lives in COPIES: the adjoint of the main launch walks ITS tape with ITS step counts
+            self.status, self.nsteps, self.nfev = sol.status.clone(), sol.nsteps.clone(), sol.nfev.clone()
+            for idx, _, s2 in extras:
+                self.y[idx], self.status[idx], self.nsteps[idx], self.nfev[idx] = s2.y, s2.status, s2.nsteps, s2.nfev
         self.n_retried = sum(int(i.numel()) for i, _, _ in extras)
 
     def backward(self, gy, want_gnn=True, want_gode=False):
@@ -145,7 +151,6 @@ def _solve_taped(x0, t, meal, tvns, gd, ode_vec, nn_flat, H, L, method, rtol, at
                 s2 = hode.solve_fwd(x0[idx].contiguous(), t[idx].contiguous() if t.dim() == 2 else t, cut(meal, idx), cut(tvns, idx),
                                     cut(gd, idx), ode_vec[17 * set_id:17 * (set_id + 1)], nn_flat[P * set_id:P * (set_id + 1)], H, L,
                                     method=method, rtol=rtol, atol=atol, n_sets=1, want_tape=True, max_steps=big)
-                sol.y[idx], sol.status[idx], sol.nsteps[idx], sol.nfev[idx] = s2.y, s2.status, s2.nsteps, s2.nfev
                 extras.append((idx, set_id, s2))
     return _Taped(sol, extras)
 

@@ -109,9 +109,20 @@ def _pool_worker(args):
     return y, c["nfev"]
 
 
-def solve_all_cores(x0, t, inputs, nn_flat, ode_vec, H=64, L=4, solver="rk45", rtol=1e-6, atol=1e-8, procs=None):
-    """The same loop spread over `procs` worker processes (patients are independent) -> (y, nfev, procs)."""
+def _pool_warm(_):
+    import scipy.integrate  # noqa: F401
+    import torch
+    torch.set_num_threads(1)
+    from models.nn_residual import NNResidual  # noqa: F401
+    return os.getpid()
+
+
+def solve_all_cores(x0, t, inputs, nn_flat, ode_vec, H=64, L=4, solver="rk45", rtol=1e-6, atol=1e-8, procs=None, timed=False):
+    """The same loop spread over `procs` worker processes (patients are independent) -> (y, nfev, procs[, seconds]).
+    timed=True also returns the wall time of the solves alone: workers are started and have imported torch / scipy before
+    the clock starts (a resident trainer would not pay that per batch)."""
     import multiprocessing as mp
+    import time
     procs = procs or (os.cpu_count() or 1)
     B = len(x0)
     procs = max(1, min(procs, B))
@@ -122,5 +133,9 @@ def solve_all_cores(x0, t, inputs, nn_flat, ode_vec, H=64, L=4, solver="rk45", r
         jobs.append((np.asarray(x0)[lo:hi], np.asarray(t)[lo:hi] if np.asarray(t).ndim == 2 else t, part, nn_flat, ode_vec, H, L,
                      solver, rtol, atol))
     with mp.get_context("spawn").Pool(procs) as pool:
-        out = pool.map(_pool_worker, jobs)
-    return np.concatenate([o[0] for o in out]), sum(o[1] for o in out), procs
+        pool.map(_pool_warm, range(4 * procs))
+        t0 = time.perf_counter()
+        out = pool.map(_pool_worker, jobs, chunksize=1)
+        dt = time.perf_counter() - t0
+    res = (np.concatenate([o[0] for o in out]), sum(o[1] for o in out), procs)
+    return res + (dt,) if timed else res
