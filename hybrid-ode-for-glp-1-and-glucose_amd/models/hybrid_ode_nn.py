@@ -537,7 +537,7 @@ class HybridODENN(nn.Module):
 
     # ------------------------------------------------------------------ ELBO (BASELINE config 5)
     def elbo(self, batch: Dict[str, torch.Tensor], n_samples: int = 16, noise_sigma: float = 0.1,
-             solver: str = "dopri5", rtol: float = 1e-6, atol: float = 1e-8, group=None) -> torch.Tensor:
+             solver: str = "dopri5", rtol: float = 1e-6, atol: float = 1e-8, group=None, return_components: bool = False):
         """Monte-Carlo ELBO of reference inference/vi.py:60-118 (`VariationalInference.elbo`):
              E_q[log p(obs | theta)] - KL[q || p],   theta_s = mu + eps_s * exp(log_sigma),  s = 1..S,
         one parameter draw shared by the whole batch per sample (vi.py:88-100).  All S x B trajectories are
@@ -548,7 +548,8 @@ class HybridODENN(nn.Module):
         group: one process per GPU, `batch` = this rank's shard of the patients, torch's RNG seeded identically on
         every rank (same draws): the data term and its gradient are summed over the group with ONE all-reduce, the KL
         term is parameter-only and computed redundantly -- every rank returns the ELBO of the whole cohort and ends the
-        backward with identical gradients."""
+        backward with identical gradients.
+        return_components: also return {'elbo', 'kl', 'log_likelihood'} (what VariationalInference.elbo hands back)."""
         if not self.use_variational:
             raise ValueError("Model was not initialized with variational inference")
         self._check_supported()
@@ -582,7 +583,8 @@ class HybridODENN(nn.Module):
                                    float(atol), S, info, group, False, self.tape_steps)
             self.last_solve_info = info
             self._warn_failures(info)
-            return (-0.5 * ss / (noise_sigma ** 2 * S) - log_norm - kl).to(self.device)
+            log_lik = -0.5 * ss / (noise_sigma ** 2 * S) - log_norm
+            return self._elbo_out(log_lik, kl, return_components)
 
         def rep(v):
             v = torch.as_tensor(v)
@@ -593,7 +595,13 @@ class HybridODENN(nn.Module):
         self._warn_failures(self.last_solve_info)
         resid = (obs.to(dev, torch.float32).repeat(S, 1, 1) - y).double() / noise_sigma
         log_lik = -0.5 * resid.pow(2).sum() / S - log_norm
-        return (log_lik - kl).to(self.device)
+        return self._elbo_out(log_lik, kl, return_components)
+
+    def _elbo_out(self, log_lik, kl, return_components):
+        elbo = (log_lik - kl).to(self.device)
+        if not return_components:
+            return elbo
+        return elbo, {"elbo": elbo, "kl": kl.to(self.device), "log_likelihood": log_lik.to(self.device)}
 
     # ------------------------------------------------------------------ loss
     def loss(self, batch: Dict[str, torch.Tensor], lambda1: float = 1.0, lambda2: float = 1.0,

@@ -247,3 +247,36 @@ def test_variational_parameters_vs_reference(golden_dir):
     for n in names["names"]:
         assert np.allclose(s[n].detach().numpy(), g["sample__" + n], rtol=1e-6, atol=1e-7)
     assert float(vp.kl_divergence().requires_grad) == 1.0
+
+
+def test_inference_package_surface_and_checkpoint_without_gpu(tmp_path):
+    """`from inference import VariationalInference` resolves to the mirror (no arviz needed); constructor contract,
+    history layout and checkpoint round trip are host-side and need no GPU; the sampler placeholders of the reference's
+    inference/mcmc.py are out of scope and say so."""
+    import torch
+    import inference
+    import models
+    from inference.vi import VariationalInference
+    assert inference.VariationalInference is VariationalInference
+    with pytest.raises(AttributeError, match="outside the accelerated path"):
+        inference.run_nuts
+    with pytest.raises(ValueError, match="use_variational=True"):
+        VariationalInference(models.HybridODENN(nn_hidden=8, nn_layers=1, device="cpu"))
+    m = models.HybridODENN(nn_hidden=8, nn_layers=1, use_variational=True, device="cpu")
+    vi = VariationalInference(m, learning_rate=5e-3, device=torch.device("cpu"))
+    assert vi.history == {"elbo": [], "kl": [], "log_likelihood": []} and vi.learning_rate == 5e-3
+    assert vi.variational_params is m.variational_params and isinstance(vi.optimizer, torch.optim.Adam)
+    assert len(vi.sample_posterior(3)) == 3
+    vi.history["elbo"].append(-1.5)
+    p = str(tmp_path / "ck.pt")
+    vi.save_checkpoint(p)
+    vi2 = VariationalInference(models.HybridODENN(nn_hidden=8, nn_layers=1, use_variational=True, device="cpu"), device=torch.device("cpu"))
+    vi2.load_checkpoint(p)
+    assert vi2.history["elbo"] == [-1.5]
+    for (k, a), (_, b) in zip(vi.variational_params.state_dict().items(), vi2.variational_params.state_dict().items()):
+        assert torch.equal(a, b), k
+    if not torch.cuda.is_available():          # the ELBO itself needs the device
+        import hode
+        batch = {"initial_state": torch.zeros(1, 6), "observations": torch.zeros(1, 3, 6), "time_points": torch.linspace(0, 1, 3)}
+        with pytest.raises(hode.HodeError):
+            vi.elbo(batch, n_samples=1)

@@ -254,7 +254,9 @@ def test_trajectories_that_outrun_the_tape_budget_are_retried_not_lost(M, golden
         ref = O.solve(x0, t, meal, tv, None, w["ode"], w["nn_flat"], 64, 4, rtol=1e-11, atol=1e-13, dtype=np.float64, want_tape=True)
         gy = 2.0 * (y0.cpu().numpy().astype(np.float64) - obs.cpu().numpy().astype(np.float64))
         _, rnn, _ = O.solve_bwd(ref, gy)
-        assert relnorm(gr, scale * rnn) < 2e-4, fused
+        # fp32 steps at a tolerance below fp32 resolution against the fp64 oracle: 3e-4 measured; a gradient that stopped at the
+        # 14-step budget would be off by O(1)
+        assert relnorm(gr, scale * rnn) < 1e-3, fused
 
 
 def test_validation_under_no_grad_and_ablations(M):
