@@ -37,6 +37,7 @@ int solve_fwd(void *stream, int B, int T, const R *x0, const R *t, int t_batched
     a.tape_seg = tape ? (int32_t *)((char *)tape + tape_seg_offset(B, max_steps, sizeof(R))) : nullptr;
     a.tape_stage = tape ? (R *)((char *)tape + tape_stage_offset(B, max_steps, sizeof(R))) : nullptr;
     a.L = L;
+    if (!tuned_shape(H, L)) return launch_solve_fwd_generic<R>((hipStream_t)stream, a, method);
     return launch_solve_fwd<R>((hipStream_t)stream, a, L, method);
 }
 
@@ -51,6 +52,7 @@ int rhs_fwd(void *stream, int B, const R *x, const R *t, const R *meal, const R 
     RhsArgs<R> a{};
     a.B = B; a.H = H; a.P = nn_param_count(H, L);
     a.x = x; a.t = t; a.meal = meal; a.tvns = tvns; a.gd = gd; a.ode_p = ode_p; a.nn_p = nn_p; a.out = out;
+    if (!tuned_shape(H, L)) return launch_rhs_fwd_generic<R>((hipStream_t)stream, a, L);
     return launch_rhs_fwd<R>((hipStream_t)stream, a, L);
 }
 
@@ -77,6 +79,7 @@ int solve_bwd(void *stream, int B, int T, const R *t, int t_batched, const R *me
     a.tape_seg = (const int32_t *)((const char *)tape + tape_seg_offset(B, max_steps, sizeof(R)));
     a.tape_stage = (const R *)((const char *)tape + tape_stage_offset(B, max_steps, sizeof(R)));
     a.gy = gy; a.gx0 = gx0; a.gnn = gnn; a.gode = gode;
+    if (!tuned_shape(H, L)) return launch_solve_bwd_generic<R>((hipStream_t)stream, a, L, method);
     return launch_solve_bwd<R>((hipStream_t)stream, a, L, method);
 }
 
@@ -92,6 +95,7 @@ int rhs_bwd(void *stream, int B, const R *x, const R *t, const R *meal, const R 
     a.B = B; a.H = H; a.P = nn_param_count(H, L);
     a.x = x; a.t = t; a.meal = meal; a.tvns = tvns; a.gd = gd; a.ode_p = ode_p; a.nn_p = nn_p;
     a.gout = gout; a.gx = gx; a.gt = gt; a.gnn = gnn; a.gode = gode;
+    if (!tuned_shape(H, L)) return launch_rhs_bwd_generic<R>((hipStream_t)stream, a, L);
     return launch_rhs_bwd<R>((hipStream_t)stream, a, L);
 }
 
@@ -99,15 +103,17 @@ int rhs_bwd(void *stream, int B, const R *x, const R *t, const R *meal, const R 
 
 extern "C" {
 
-const char *hode_version(void) { return "hode 0.1.0 (gfx950; wave-per-trajectory DP5(4) + adjoint)"; }
+const char *hode_version(void) { return "hode 0.2.0 (gfx950; wave-per-trajectory DP5(4) + adjoint; MLP up to 8 x 128)"; }
 
 int hode_nn_param_count(int H, int L) { return (H < 1 || L < 1) ? HODE_EINVAL : nn_param_count(H, L); }
 
-size_t hode_tape_bytes(int B, int max_steps, int elem_size, int L)
+size_t hode_tape_bytes_hl(int B, int max_steps, int elem_size, int H, int L)
 {
-    if (B < 0 || max_steps < 0 || (elem_size != 4 && elem_size != 8) || L < 1 || L > HODE_MAX_LAYERS) return 0;
-    return tape_total_bytes(B, max_steps, (size_t)elem_size, L);
+    if (B < 0 || max_steps < 0 || (elem_size != 4 && elem_size != 8) || H < 1 || H > HODE_MAX_HIDDEN || L < 1 || L > HODE_MAX_LAYERS)
+        return 0;
+    return tape_total_bytes(B, max_steps, (size_t)elem_size, H, L);
 }
+size_t hode_tape_bytes(int B, int max_steps, int elem_size, int L) { return hode_tape_bytes_hl(B, max_steps, elem_size, 64, L); }
 
 int hode_rhs_fwd_f32(void *stream, int B, const float *x, const float *t, const float *meal, const float *tvns,
                      const float *gd, const float *ode_p, const float *nn_p, int H, int L, float *out)

@@ -522,6 +522,22 @@ __device__ __forceinline__ void mlp_outer_acc(double (&gw)[kMaxH], double d, dou
 template <typename R, int NL> struct MlpActs { R h[NL]; };
 
 // ------------------------------------------------------------------------------------------
+// Mechanistic part (models/ode_core.py:124-153), evaluated redundantly on every lane from the broadcast state; the lane
+// keeps the component of its slot c8 = lane & 7 (GE, slot 4, has no dynamics; slots 6, 7 are padding).
+template <typename R>
+__device__ __forceinline__ R mech_eval(const OdeP<R> &o, R G, R I, R Glu, R GLP1, R FFA, R meal, R gde, int c8)
+{
+    const R Pi = R(1) + o.rho * GLP1;
+    const R dI = Pi * o.a_GI * (G - o.G_b) - o.k_I * (I - o.I_b);
+    const R dGlu = -(o.E_max * rdiv(GLP1, o.EC_50 + GLP1)) * (Glu - o.Glu_b);
+    const R dGLP1 = o.V_max * rdiv(G, o.K_m + G) - o.k_L * GLP1;
+    const R k_GE = o.k_GE0 * (R(1) - gde);
+    const R dFFA = -o.p_7 * FFA - o.p_8 * I * FFA + o.p_9 * G * FFA;
+    const R dG = meal - R(0.01) * (I - o.I_b) + R(0.005) * (Glu - o.Glu_b) - k_GE * G;
+    return (c8 == 0) ? dG : (c8 == 1) ? dI : (c8 == 2) ? dGlu : (c8 == 3) ? dGLP1 : (c8 == 5) ? dFFA : R(0);
+}
+
+// ------------------------------------------------------------------------------------------
 // RHS  f(t, x, u) = ODECore + NNResidual  (models/hybrid_ode_nn.py:108-134)
 //   Y   lane-distributed state: lane l holds x_{l&7} (replicated over the eight 8-lane groups;
 //       only lanes 0..5 are read)
@@ -533,16 +549,8 @@ __device__ __forceinline__ R rhs_eval(const WT &W, const OdeP<R> &o, R t, R Y, R
 {
     const R G = lane_bcast(Y, 0), I = lane_bcast(Y, 1), Glu = lane_bcast(Y, 2), GLP1 = lane_bcast(Y, 3),
             GE = lane_bcast(Y, 4), FFA = lane_bcast(Y, 5);
-    // ---- mechanistic part (models/ode_core.py:124-153), evaluated redundantly on every lane
-    const R Pi = R(1) + o.rho * GLP1;
-    const R dI = Pi * o.a_GI * (G - o.G_b) - o.k_I * (I - o.I_b);
-    const R dGlu = -(o.E_max * rdiv(GLP1, o.EC_50 + GLP1)) * (Glu - o.Glu_b);
-    const R dGLP1 = o.V_max * rdiv(G, o.K_m + G) - o.k_L * GLP1;
-    const R k_GE = o.k_GE0 * (R(1) - gde);
-    const R dFFA = -o.p_7 * FFA - o.p_8 * I * FFA + o.p_9 * G * FFA;
-    const R dG = meal - R(0.01) * (I - o.I_b) + R(0.005) * (Glu - o.Glu_b) - k_GE * G;
     const int c8 = lane & 7;
-    R mech = (c8 == 0) ? dG : (c8 == 1) ? dI : (c8 == 2) ? dGlu : (c8 == 3) ? dGLP1 : (c8 == 5) ? dFFA : R(0);
+    const R mech = mech_eval(o, G, I, Glu, GLP1, FFA, meal, gde, c8);
     // ---- MLP (models/nn_residual.py:138-147): input row [t, G, I, Glu, GLP1, GE, FFA, glp1:=GLP1, tvns]
     R h = W.b[0];
     h = rfma(W.w1[0], t, h);
@@ -853,23 +861,13 @@ __device__ __forceinline__ void hidden_flush(const R (&wh)[(NL > 1) ? NL - 1 : 1
     }
 }
 
-// VJP of rhs_eval.  kb = cotangent of f (replicated layout); returns the cotangent of the state in the
-// same layout and accumulates parameter gradients.  acts = activations of this evaluation (from
-// rhs_eval<KEEP> or from the stage tape).  Needs only the first/last layer weights in registers;
-// the hidden matrices come transposed from LDS (wt).   GODE: also d/d(ode constants) (wave-uniform values).
-template <typename R, int NL, bool GODE, bool GT, typename Edge, typename Wt>
-__device__ __forceinline__ R rhs_vjp(Edge &e, R (&gwh)[(NL > 1) ? NL - 1 : 1][kMaxH], const Wt &wt,
-                                     const OdeP<R> &o, R t, R Y, R tvns, R gde, R gd_in, bool use_gd, int lane,
-                                     const MlpActs<R, NL> &acts, R kb, R &go, R *gt_out)
+// J_mech^T kb (analytic Jacobian of models/ode_core.py:124-153) in the replicated layout; GODE: also d f / d(ode constant p) . kb
+// for the 17 constants, accumulated LANE-DISTRIBUTED: lane p < 17 of the single register `go` holds the running sum for
+// constant p (17 separate uniform accumulators cost 16 more VGPRs, which the adjoint kernel does not have).
+template <typename R, bool GODE>
+__device__ __forceinline__ R mech_vjp(const OdeP<R> &o, R G, R I, R Glu, R GLP1, R FFA, R lG, R lI, R lGlu, R lGLP, R lF, R gde,
+                                      R gd_in, bool use_gd, int lane, R &go)
 {
-    using S = EdgeSlots<NL>;
-    // increments of the edge-parameter gradients are collected and applied in ONE batch at the end
-    R inc[S::count];
-    const R G = lane_bcast(Y, 0), I = lane_bcast(Y, 1), Glu = lane_bcast(Y, 2), GLP1 = lane_bcast(Y, 3),
-            GE = lane_bcast(Y, 4), FFA = lane_bcast(Y, 5);
-    const R lG = lane_bcast(kb, 0), lI = lane_bcast(kb, 1), lGlu = lane_bcast(kb, 2), lGLP = lane_bcast(kb, 3),
-            lGE = lane_bcast(kb, 4), lF = lane_bcast(kb, 5);
-    // ---- mechanistic J^T kb (analytic Jacobian of models/ode_core.py:124-153)
     const R Pi = R(1) + o.rho * GLP1;
     const R den1 = o.EC_50 + GLP1, den2 = o.K_m + G;
     const R k_GE = o.k_GE0 * (R(1) - gde);
@@ -882,9 +880,6 @@ __device__ __forceinline__ R rhs_vjp(Edge &e, R (&gwh)[(NL > 1) ? NL - 1 : 1][kM
     const int c8 = lane & 7;
     const R mech = (c8 == 0) ? oG : (c8 == 1) ? oI : (c8 == 2) ? oGlu : (c8 == 3) ? oGLP : (c8 == 5) ? oF : R(0);
     if constexpr (GODE) {
-        // d f / d(ode constant p) . kb for the 17 constants (wave-uniform values), accumulated LANE-DISTRIBUTED:
-        // lane p < 17 of the single register `go` holds the running sum for constant p (17 separate uniform
-        // accumulators cost 16 more VGPRs, which this kernel does not have)
         R c[17];
         c[0] = lI * Pi * (G - o.G_b);
         c[1] = -lI * (I - o.I_b);
@@ -913,6 +908,27 @@ __device__ __forceinline__ R rhs_vjp(Edge &e, R (&gwh)[(NL > 1) ? NL - 1 : 1][kM
         for (int p = 0; p < 17; ++p) sel = (lane == p) ? c[p] : sel;
         go += sel;
     }
+    return mech;
+}
+
+// VJP of rhs_eval.  kb = cotangent of f (replicated layout); returns the cotangent of the state in the
+// same layout and accumulates parameter gradients.  acts = activations of this evaluation (from
+// rhs_eval<KEEP> or from the stage tape).  Needs only the first/last layer weights in registers;
+// the hidden matrices come transposed from LDS (wt).   GODE: also d/d(ode constants) (wave-uniform values).
+template <typename R, int NL, bool GODE, bool GT, typename Edge, typename Wt>
+__device__ __forceinline__ R rhs_vjp(Edge &e, R (&gwh)[(NL > 1) ? NL - 1 : 1][kMaxH], const Wt &wt,
+                                     const OdeP<R> &o, R t, R Y, R tvns, R gde, R gd_in, bool use_gd, int lane,
+                                     const MlpActs<R, NL> &acts, R kb, R &go, R *gt_out)
+{
+    using S = EdgeSlots<NL>;
+    // increments of the edge-parameter gradients are collected and applied in ONE batch at the end
+    R inc[S::count];
+    const R G = lane_bcast(Y, 0), I = lane_bcast(Y, 1), Glu = lane_bcast(Y, 2), GLP1 = lane_bcast(Y, 3),
+            GE = lane_bcast(Y, 4), FFA = lane_bcast(Y, 5);
+    const R lG = lane_bcast(kb, 0), lI = lane_bcast(kb, 1), lGlu = lane_bcast(kb, 2), lGLP = lane_bcast(kb, 3),
+            lGE = lane_bcast(kb, 4), lF = lane_bcast(kb, 5);
+    const int c8 = lane & 7;
+    const R mech = mech_vjp<R, GODE>(o, G, I, Glu, GLP1, FFA, lG, lI, lGlu, lGLP, lF, gde, gd_in, use_gd, lane, go);
     // ---- MLP backward
     const R hl = acts.h[NL - 1];
     // fetch the six output-layer weights in one batch (LDS policy: six reads in flight, one wait)

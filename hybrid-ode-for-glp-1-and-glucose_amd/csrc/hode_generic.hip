@@ -1,0 +1,380 @@
+// hode_generic.hip -- the GENERIC network path: K1 / K2+K3 / K4 / K5 for every MLP shape outside the tuned envelope,
+// up to hidden width 128 and 8 hidden layers (reference configs/ablation_no_physics.yaml:11-12 trains nn_hidden 128,
+// nn_layers 5; models/nn_residual.py:28-98 builds any width / depth).
+//
+// The tuned kernels (hode_solve_fwd.hip, hode_solve_bwd.hip) keep a 4 x 64 network in registers: 211 weight registers
+// per lane, gradient accumulators in registers, matrices compiled in as template parameters.  A 5 x 128 network has
+// 67 k parameters (270 KB): it fits neither the register file of a wave nor the 160 KB of LDS.  So here
+//   * the mapping stays ONE TRAJECTORY PER WAVEFRONT, and every lane owns TWO hidden units, j and j + 64;
+//   * weights are STREAMED from L2 at every evaluation, natural PyTorch layout: in the forward product lane j walks
+//     its rows j and j + 64 while the activation h_k arrives by v_readlane; in the transposed product lane k reads
+//     W[j][k] and W[j][k + 64] -- 256 contiguous bytes per wave load;
+//   * parameter gradients leave through coalesced global atomics (dW[j][:] += delta_j * h[:], one 256-byte atomic
+//     wave-instruction per matrix row and half), skipped when delta_j is exactly zero (ReLU);
+//   * depth is a run-time loop, layer activations go straight to the stage tape ((2 L + 1) rows of 64 per stage).
+// It is built for the batches the reference trains such shapes with (32 patients x 61 grid points): the adjoint moves
+// ~280 KB of atomics per stage, which at the chip's ~1.3 TB/s of float atomics is 2-3 ms for that batch and grows
+// linearly with B x T.  The integrator, controller, tape format and state layout are those of the tuned path
+// (hode_solve_body.h); CPU restatement: oracle/hode_oracle_impl.h (HODE_MAXH 128, HODE_MAXL 8).
+#include "hode_solve_body.h"
+
+namespace hode {
+
+// one parameter set in the flat PyTorch parameters() layout (include/hode.h)
+template <typename R> struct StreamNet {
+    const R *p;
+    int H, L;
+    __device__ __forceinline__ const R *W1() const { return p; }                       // [H][9]
+    __device__ __forceinline__ const R *b1() const { return p + 9 * H; }
+    __device__ __forceinline__ size_t hid_off(int l) const { return (size_t)9 * H + H + (size_t)l * ((size_t)H * H + H); }
+    __device__ __forceinline__ const R *Wh(int l) const { return p + hid_off(l); }       // hidden matrix l = 0..L-2: [H][H]
+    __device__ __forceinline__ const R *bh(int l) const { return Wh(l) + (size_t)H * H; }
+    __device__ __forceinline__ size_t out_off() const { return hid_off(L - 1); }
+    __device__ __forceinline__ const R *Wo() const { return p + out_off(); }             // [6][H]
+    __device__ __forceinline__ const R *bo() const { return Wo() + 6 * H; }
+};
+
+__device__ __forceinline__ float bcast_dyn(float v, int k) { return i2f(__builtin_amdgcn_readlane(f2i(v), k)); }
+__device__ __forceinline__ double bcast_dyn(double v, int k) { return lane_bcast(v, k); }
+// activation k of a layer whose units live two per lane (k < 64: register a of lane k; else register b of lane k - 64)
+template <typename R> __device__ __forceinline__ R unit_bcast(R a, R b, int k) { return k < 64 ? bcast_dyn(a, k) : bcast_dyn(b, k - 64); }
+
+// f(t, x, u) for an arbitrary network.  rec != nullptr: record h_1..h_L (two rows of 64 each) and the stage state.
+template <typename R>
+__device__ __forceinline__ R rhs_stream(const StreamNet<R> &n, const OdeP<R> &o, R t, R Y, R meal, R tvns, R gde, int lane,
+                                        R *__restrict__ rec)
+{
+    const int H = n.H, L = n.L;
+    const R G = lane_bcast(Y, 0), I = lane_bcast(Y, 1), Glu = lane_bcast(Y, 2), GLP1 = lane_bcast(Y, 3),
+            GE = lane_bcast(Y, 4), FFA = lane_bcast(Y, 5);
+    const int c8 = lane & 7;
+    const R mech = mech_eval(o, G, I, Glu, GLP1, FFA, meal, gde, c8);
+    const bool vA = lane < H, vB = lane + 64 < H;
+    const int jA = vA ? lane : 0, jB = vB ? lane + 64 : 0;              // clamped: masked lanes read a valid address
+    const R in[9] = {t, G, I, Glu, GLP1, GE, FFA, GLP1, tvns};          // models/nn_residual.py:138-143
+    R hA = n.b1()[jA], hB = n.b1()[jB];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        hA = rfma(n.W1()[jA * 9 + i], in[i], hA);
+        hB = rfma(n.W1()[jB * 9 + i], in[i], hB);
+    }
+    hA = vA ? rmax0(hA) : R(0);
+    hB = vB ? rmax0(hB) : R(0);
+    if (rec) { rec[lane] = hA; rec[kWave + lane] = hB; }
+    for (int l = 0; l + 1 < L; ++l) {
+        const R *__restrict__ rowA = n.Wh(l) + (size_t)jA * H, *__restrict__ rowB = n.Wh(l) + (size_t)jB * H;
+        R aA = n.bh(l)[jA], aB = n.bh(l)[jB];
+        const int H0 = H < 64 ? H : 64;
+        for (int k = 0; k < H0; ++k) {                          // units 0..63 live in hA
+            const R hk = bcast_dyn(hA, k);
+            aA = rfma(rowA[k], hk, aA);
+            aB = rfma(rowB[k], hk, aB);
+        }
+        for (int k = 64; k < H; ++k) {                          // units 64..127 in hB
+            const R hk = bcast_dyn(hB, k - 64);
+            aA = rfma(rowA[k], hk, aA);
+            aB = rfma(rowB[k], hk, aB);
+        }
+        hA = vA ? rmax0(aA) : R(0);
+        hB = vB ? rmax0(aB) : R(0);
+        if (rec) { rec[(2 * (l + 1)) * kWave + lane] = hA; rec[(2 * (l + 1) + 1) * kWave + lane] = hB; }
+    }
+    R p[6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) p[q] = n.Wo()[q * H + jA] * hA + n.Wo()[q * H + jB] * hB;     // h is 0 on masked lanes
+    const R nn = wave_reduce6_to_lanes(p, lane);
+    if (rec) rec[2 * L * kWave + lane] = Y;
+    const R bout = (c8 < 6) ? n.bo()[(c8 < 6) ? c8 : 0] : R(0);
+    return (c8 < 6) ? (mech + nn + bout) : R(0);
+}
+
+template <typename R> struct RhsStream {
+    StreamNet<R> n;
+    const OdeP<R> &o;
+    int lane;
+    __device__ __forceinline__ int slot_elems() const { return (2 * n.L + 1) * kWave; }
+    __device__ __forceinline__ R operator()(R ts, R Ys, R meal, R tvns, R gde, R *__restrict__ rec) const
+    {
+        return rhs_stream<R>(n, o, ts, Ys, meal, tvns, gde, lane, rec);
+    }
+};
+
+// J^T kb for an arbitrary network from a stage record.  g: gradient vector of this parameter set (or nullptr).
+template <typename R, bool GODE, bool GT>
+__device__ __forceinline__ R rhs_vjp_stream(const StreamNet<R> &n, R *__restrict__ g, const OdeP<R> &o, R t, R tvns, R gde, R gd_in,
+                                            bool use_gd, int lane, const R *__restrict__ rec, R kb, R &go, R *gt_out)
+{
+    const int H = n.H, L = n.L;
+    const R Y = rec[2 * L * kWave + lane];
+    const R G = lane_bcast(Y, 0), I = lane_bcast(Y, 1), Glu = lane_bcast(Y, 2), GLP1 = lane_bcast(Y, 3),
+            GE = lane_bcast(Y, 4), FFA = lane_bcast(Y, 5);
+    const R lq[6] = {lane_bcast(kb, 0), lane_bcast(kb, 1), lane_bcast(kb, 2), lane_bcast(kb, 3), lane_bcast(kb, 4), lane_bcast(kb, 5)};
+    const int c8 = lane & 7;
+    const R mech = mech_vjp<R, GODE>(o, G, I, Glu, GLP1, FFA, lq[0], lq[1], lq[2], lq[3], lq[5], gde, gd_in, use_gd, lane, go);
+    const bool vA = lane < H, vB = lane + 64 < H;
+    const int jA = vA ? lane : 0, jB = vB ? lane + 64 : 0;
+    // output layer
+    R hA = rec[(2 * (L - 1)) * kWave + lane], hB = rec[(2 * (L - 1) + 1) * kWave + lane];
+    R dA = R(0), dB = R(0);
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        dA = rfma(n.Wo()[q * H + jA], lq[q], dA);
+        dB = rfma(n.Wo()[q * H + jB], lq[q], dB);
+        if (g) {
+            if (vA) atomic_add(g + n.out_off() + q * H + jA, lq[q] * hA);
+            if (vB) atomic_add(g + n.out_off() + q * H + jB, lq[q] * hB);
+        }
+    }
+    if (g && lane < 6) atomic_add(g + n.out_off() + 6 * H + lane, kb);
+    dA = (vA && hA > R(0)) ? dA : R(0);
+    dB = (vB && hB > R(0)) ? dB : R(0);
+    // hidden matrices, last to first: matrix l maps h_l (rows 2l, 2l+1 of the record) to h_{l+1}
+    for (int l = L - 2; l >= 0; --l) {
+        const R inA = rec[(2 * l) * kWave + lane], inB = rec[(2 * l + 1) * kWave + lane];
+        const R *__restrict__ W = n.Wh(l);
+        R *__restrict__ gW = g ? g + n.hid_off(l) : nullptr;
+        if (g) {
+            if (vA) atomic_add(gW + (size_t)H * H + jA, dA);
+            if (vB) atomic_add(gW + (size_t)H * H + jB, dB);
+        }
+        R pA = R(0), pB = R(0);
+        for (int j = 0; j < H; ++j) {
+            const R dj = unit_bcast(dA, dB, j);
+            if (dj == R(0)) continue;                          // wave-uniform: dead unit (ReLU) -- nothing to add, nothing to propagate
+            const R *__restrict__ row = W + (size_t)j * H;
+            pA = rfma(row[jA], dj, pA);                         // column jA / jB of row j: 256 contiguous bytes per wave
+            pB = rfma(row[jB], dj, pB);
+            if (g) {
+                if (vA) atomic_add(gW + (size_t)j * H + jA, dj * inA);
+                if (vB) atomic_add(gW + (size_t)j * H + jB, dj * inB);
+            }
+        }
+        dA = (vA && inA > R(0)) ? pA : R(0);
+        dB = (vB && inB > R(0)) ? pB : R(0);
+    }
+    // first layer: input row [t, G, I, Glu, GLP1, GE, FFA, glp1 := GLP1, tvns]
+    const R in[9] = {t, G, I, Glu, GLP1, GE, FFA, GLP1, tvns};
+    if (g) {
+        if (vA) atomic_add(g + 9 * H + jA, dA);
+        if (vB) atomic_add(g + 9 * H + jB, dB);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            if (vA) atomic_add(g + jA * 9 + i, dA * in[i]);
+            if (vB) atomic_add(g + jB * 9 + i, dB * in[i]);
+        }
+    }
+    R w[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) w[i] = n.W1()[jA * 9 + i] * dA + n.W1()[jB * 9 + i] * dB;       // d is 0 on masked lanes
+    const R p[6] = {w[1], w[2], w[3], w[4] + w[7], w[5], w[6]};                                   // GLP1 feeds inputs 4 and 7
+    const R nn = wave_reduce6_to_lanes(p, lane);
+    if constexpr (GT) *gt_out = wave_allsum(w[0]);
+    return (c8 < 6) ? (mech + nn) : R(0);
+}
+
+// ------------------------------------------------------------------------------------------ K1 / K5
+template <typename R>
+__global__ __launch_bounds__(256) void rhs_fwd_generic_kernel(const RhsArgs<R> a, int L)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = first_lane((int)(threadIdx.x >> 6));
+    const StreamNet<R> n{a.nn_p, a.H, L};
+    OdeP<R> o;
+    ode_load(o, a.ode_p);
+    for (int s = blockIdx.x * 4 + wave; s < a.B; s += gridDim.x * 4) {
+        const R Y = (lane < 6) ? a.x[(size_t)s * 6 + lane] : R(0);
+        const R gde = a.gd ? gd_effect(o, a.gd[s]) : R(0);
+        const R F = rhs_stream<R>(n, o, a.t ? a.t[s] : R(0), Y, a.meal ? a.meal[s] : R(0), a.tvns ? a.tvns[s] : R(0), gde, lane, nullptr);
+        if (lane < 6) a.out[(size_t)s * 6 + lane] = F;
+    }
+}
+
+template <typename R, bool GODE>
+__global__ __launch_bounds__(256) void rhs_bwd_generic_kernel(const RhsArgs<R> a, int L)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int lane = threadIdx.x & 63;
+    const int wave = first_lane((int)(threadIdx.x >> 6));
+    R *rec = reinterpret_cast<R *>(smem_raw) + (size_t)wave * (2 * L + 1) * kWave;      // this wave's record
+    const StreamNet<R> n{a.nn_p, a.H, L};
+    OdeP<R> o;
+    ode_load(o, a.ode_p);
+    R go = R(0);
+    for (int s = blockIdx.x * 4 + wave; s < a.B; s += gridDim.x * 4) {
+        const R Y = (lane < 6) ? a.x[(size_t)s * 6 + lane] : R(0);
+        const R kb = (lane < 6) ? a.gout[(size_t)s * 6 + lane] : R(0);
+        const R t = a.t ? a.t[s] : R(0), tvns = a.tvns ? a.tvns[s] : R(0), gdv = a.gd ? a.gd[s] : R(0);
+        const R gde = a.gd ? gd_effect(o, gdv) : R(0);
+        (void)rhs_stream<R>(n, o, t, Y, a.meal ? a.meal[s] : R(0), tvns, gde, lane, rec);
+        __builtin_amdgcn_wave_barrier();
+        R gt;
+        const R Z = rhs_vjp_stream<R, GODE, true>(n, a.gnn, o, t, tvns, gde, gdv, a.gd != nullptr, lane, rec, kb, go, &gt);
+        __builtin_amdgcn_wave_barrier();
+        if (lane < 6) a.gx[(size_t)s * 6 + lane] = Z;
+        if (a.gt && lane == 0) a.gt[s] = gt;
+    }
+    if constexpr (GODE) {
+        if (a.gode && lane < 17) atomic_add(a.gode + lane, go);
+    }
+}
+
+template <typename R> int launch_rhs_fwd_generic(hipStream_t s, const RhsArgs<R> &a, int L)
+{
+    int blocks = (a.B + 3) / 4;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) return HODE_OK;
+    hipLaunchKernelGGL((rhs_fwd_generic_kernel<R>), dim3(blocks), dim3(256), 0, s, a, L);
+    return hipGetLastError() == hipSuccess ? HODE_OK : HODE_ELAUNCH;
+}
+template <typename R> int launch_rhs_bwd_generic(hipStream_t s, const RhsArgs<R> &a, int L)
+{
+    int blocks = (a.B + 3) / 4;
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) return HODE_OK;
+    const size_t lds = (size_t)4 * (2 * L + 1) * kWave * sizeof(R);
+    if (a.gode) hipLaunchKernelGGL((rhs_bwd_generic_kernel<R, true>), dim3(blocks), dim3(256), lds, s, a, L);
+    else hipLaunchKernelGGL((rhs_bwd_generic_kernel<R, false>), dim3(blocks), dim3(256), lds, s, a, L);
+    return hipGetLastError() == hipSuccess ? HODE_OK : HODE_ELAUNCH;
+}
+
+// ------------------------------------------------------------------------------------------ K2 + K3
+template <typename R, int METHOD, bool TAPE, bool GD>
+__global__ __launch_bounds__(64) void solve_fwd_generic_kernel(const SolveArgs<R> a)
+{
+    __shared__ R rows[8 * kWave];
+    __shared__ R cvec[8];
+    __shared__ R ybuf[kWave + 8];
+    const int lane = threadIdx.x;
+    const int b = blockIdx.x;
+    const int set = b / (a.B / a.n_sets);
+    tableau_rows_store<R>(rows, METHOD, lane, 64);
+    if (lane < 8) cvec[lane] = (R)kTableau[METHOD].c[lane];
+    OdeP<R> o;
+    ode_load(o, a.ode_p + 17 * set);
+    __syncthreads();
+    const RhsStream<R> rhs{StreamNet<R>{a.nn_p + (size_t)set * a.P, a.H, a.L}, o, lane};
+    solve_one<R, METHOD, TAPE, GD>(a, b, rhs, o, rows, cvec, ybuf, lane);
+}
+
+template <typename R, int METHOD> static int launch_fwd_generic_m(hipStream_t s, const SolveArgs<R> &a)
+{
+    const bool tape = a.tape != nullptr, gd = a.gd_mode != 0;
+    const dim3 grid(a.B), block(64);
+    if (tape) {
+        if (gd) hipLaunchKernelGGL((solve_fwd_generic_kernel<R, METHOD, true, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((solve_fwd_generic_kernel<R, METHOD, true, false>), grid, block, 0, s, a);
+    } else {
+        if (gd) hipLaunchKernelGGL((solve_fwd_generic_kernel<R, METHOD, false, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((solve_fwd_generic_kernel<R, METHOD, false, false>), grid, block, 0, s, a);
+    }
+    return hipGetLastError() == hipSuccess ? HODE_OK : HODE_ELAUNCH;
+}
+template <typename R> int launch_solve_fwd_generic(hipStream_t s, const SolveArgs<R> &a, int method)
+{
+    return method == HODE_METHOD_DP54 ? launch_fwd_generic_m<R, HODE_METHOD_DP54>(s, a) : launch_fwd_generic_m<R, HODE_METHOD_RK4>(s, a);
+}
+
+// ------------------------------------------------------------------------------------------ K4
+// Same walk over the tape as solve_bwd_kernel (hode_solve_bwd.hip); records are read from HBM with plain loads (L2 hits:
+// the forward has just written them), gradients leave through atomics inside rhs_vjp_stream.
+template <typename R, bool GODE, bool GD>
+__global__ __launch_bounds__(64) void solve_bwd_generic_kernel(const AdjArgs<R> a, const int method, const int L)
+{
+    __shared__ R rowsT[8 * kWave];
+    const int lane = threadIdx.x;
+    const int c8 = lane & 7, grp = lane >> 3;
+    const int T = a.T;
+    const TableauData &tab = kTableau[method];
+    const int S = tab.S;
+    const int kSlot = (2 * L + 1) * kWave;
+    tableau_rowsT_store<R>(rowsT, method, lane, 64);
+    __syncthreads();
+    const int per_set = a.B / a.n_sets;
+    constexpr bool use_gd = GD;
+    for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+        const int set = b / per_set;
+        const StreamNet<R> n{a.nn_p + (size_t)set * a.P, a.H, L};
+        R *__restrict__ g = a.gnn ? a.gnn + (size_t)set * a.P : nullptr;
+        OdeP<R> o;
+        ode_load(o, a.ode_p + 17 * set);
+        const R *__restrict__ tg = a.t + (a.t_batched ? (size_t)b * T : 0);
+        const R *__restrict__ tape = a.tape + (size_t)b * a.max_steps * 8;
+        const int *__restrict__ tseg = a.tape_seg + (size_t)b * a.max_steps;
+        const R *__restrict__ stg = a.tape_stage + (size_t)b * a.max_steps * 6 * kSlot;
+        const R *__restrict__ gyb = a.gy + (size_t)b * T * 6;
+        const int nst = a.nsteps[b] < a.max_steps ? a.nsteps[b] : a.max_steps;
+        const bool ok = a.status[b] == HODE_ST_OK;
+        auto gy_row = [&](int r) -> R { return (c8 < 6) ? gyb[(size_t)r * 6 + c8] : R(0); };
+        R lam = R(0), go = R(0);
+        int knext = T - 1;
+        for (int st = nst - 1; st >= 0; --st) {
+            const int kraw = tseg[st];
+            const int k = kraw & (kSegClosed - 1);
+            int hi = knext;                                   // rows this step produced: see solve_bwd_kernel
+            if (st == nst - 1) {
+                hi = T - 1;
+                if (!ok) {
+                    hi = k;
+                    if (kraw & kSegClosed) {
+                        hi = k + 1;
+                        while (hi + 1 < T && !(tg[hi + 1] > tg[hi])) ++hi;
+                    }
+                }
+            }
+            for (int r = k + 1; r <= hi; ++r) lam += gy_row(r);
+            knext = k;
+            const R tc = tape[(size_t)st * 8 + 0], h = tape[(size_t)st * 8 + 1];
+            const R t0 = tg[k], t1 = tg[k + 1];
+            const R v0 = inp_at(a.tvns, a.tvns_mode, b, T, k), v1 = inp_at(a.tvns, a.tvns_mode, b, T, k + 1);
+            const R d0 = inp_at(a.gd, a.gd_mode, b, T, k), d1 = inp_at(a.gd, a.gd_mode, b, T, k + 1);
+            const R inv_len = first_lane(R(1) / (t1 - t0));
+            const R dv = first_lane(v1 - v0), dd = first_lane(d1 - d0);
+            R ZZ = R(0);
+            for (int s = S - 1; s >= 0; --s) {
+                const R bw_s = rowsT[6 * kWave + s], c_s = rowsT[6 * kWave + 8 + s];
+                const R kb = h * rfma(bw_s, lam, group_sum8(rowsT[s * kWave + lane] * ZZ));
+                const R ts = rfma(c_s, h, tc);
+                const R al = (ts - t0) * inv_len;
+                const R gdv = rfma(al, dd, d0);
+                R gde = R(0);
+                if constexpr (use_gd) gde = gd_effect(o, gdv);
+                const R Z = rhs_vjp_stream<R, GODE, false>(n, g, o, ts, rfma(al, dv, v0), gde, gdv, use_gd, lane,
+                                                           stg + ((size_t)st * 6 + s) * kSlot, kb, go, nullptr);
+                ZZ = (grp == s) ? Z : ZZ;
+            }
+            lam += group_sum8(rowsT[7 * kWave + lane] * ZZ);
+        }
+        int kf = 0;                                           // rows 0..kf are (copies of) x0
+        while (kf + 1 < T && !(tg[kf + 1] > tg[kf])) ++kf;
+        for (int r = 0; r <= kf; ++r) lam += gy_row(r);
+        if (lane < 6) a.gx0[(size_t)b * 6 + lane] = lam;
+        if constexpr (GODE) {
+            if (a.gode && lane < 17) atomic_add(a.gode + 17 * set + lane, go);
+        }
+    }
+}
+
+template <typename R> int launch_solve_bwd_generic(hipStream_t s, const AdjArgs<R> &a, int L, int method)
+{
+    const dim3 grid(a.B < 4096 ? a.B : 4096), block(64);
+    const bool gd = a.gd_mode != 0;
+    if (a.gode) {
+        if (gd) hipLaunchKernelGGL((solve_bwd_generic_kernel<R, true, true>), grid, block, 0, s, a, method, L);
+        else hipLaunchKernelGGL((solve_bwd_generic_kernel<R, true, false>), grid, block, 0, s, a, method, L);
+    } else {
+        if (gd) hipLaunchKernelGGL((solve_bwd_generic_kernel<R, false, true>), grid, block, 0, s, a, method, L);
+        else hipLaunchKernelGGL((solve_bwd_generic_kernel<R, false, false>), grid, block, 0, s, a, method, L);
+    }
+    return hipGetLastError() == hipSuccess ? HODE_OK : HODE_ELAUNCH;
+}
+
+template int launch_rhs_fwd_generic<float>(hipStream_t, const RhsArgs<float> &, int);
+template int launch_rhs_fwd_generic<double>(hipStream_t, const RhsArgs<double> &, int);
+template int launch_rhs_bwd_generic<float>(hipStream_t, const RhsArgs<float> &, int);
+template int launch_rhs_bwd_generic<double>(hipStream_t, const RhsArgs<double> &, int);
+template int launch_solve_fwd_generic<float>(hipStream_t, const SolveArgs<float> &, int);
+template int launch_solve_fwd_generic<double>(hipStream_t, const SolveArgs<double> &, int);
+template int launch_solve_bwd_generic<float>(hipStream_t, const AdjArgs<float> &, int, int);
+template int launch_solve_bwd_generic<double>(hipStream_t, const AdjArgs<double> &, int, int);
+
+}  // namespace hode

@@ -42,6 +42,13 @@ int launch_solve_fwd_wg(hipStream_t s, const SolveArgs<float> &a, int L, int met
 template <typename R> int launch_solve_bwd(hipStream_t s, const AdjArgs<R> &a, int L, int method);
 template <typename R> int launch_rhs_fwd(hipStream_t s, const RhsArgs<R> &a, int L);
 template <typename R> int launch_rhs_bwd(hipStream_t s, const RhsArgs<R> &a, int L);
+// generic network path (hode_generic.hip): H <= 128, L <= 8, weights streamed from L2
+template <typename R> int launch_solve_fwd_generic(hipStream_t s, const SolveArgs<R> &a, int method);
+template <typename R> int launch_solve_bwd_generic(hipStream_t s, const AdjArgs<R> &a, int L, int method);
+template <typename R> int launch_rhs_fwd_generic(hipStream_t s, const RhsArgs<R> &a, int L);
+template <typename R> int launch_rhs_bwd_generic(hipStream_t s, const RhsArgs<R> &a, int L);
+// shapes the tuned (register-resident) kernels are compiled for; everything else up to HODE_MAX_* takes the generic path
+inline bool tuned_shape(int H, int L) { return H <= 64 && L <= 4; }
 int launch_adam(hipStream_t s, int64_t n, float *p, const float *g, float *m, float *v, float lr, float b1,
                 float b2, float eps, int step, float max_norm, float grad_scale, float wd, void *scratch);
 int launch_mse(hipStream_t s, int64_t n, const float *y, const float *obs, float scale, double *loss, float *gy);
@@ -91,9 +98,11 @@ inline size_t tape_stage_offset(int B, int max_steps, size_t elem)
     size_t o = tape_seg_offset(B, max_steps, elem) + (size_t)B * max_steps * sizeof(int32_t);
     return (o + 255) & ~(size_t)255;
 }
-inline size_t tape_total_bytes(int B, int max_steps, size_t elem, int L)
+// reals per stage record: tuned path (L + 1) rows of 64 (one hidden unit per lane), generic path (2 L + 1) rows (two per lane)
+inline size_t tape_slot_elems(int H, int L) { return (size_t)(tuned_shape(H, L) ? L + 1 : 2 * L + 1) * 64; }
+inline size_t tape_total_bytes(int B, int max_steps, size_t elem, int H, int L)
 {
-    return tape_stage_offset(B, max_steps, elem) + (size_t)B * max_steps * 6 * (L + 1) * 64 * elem;
+    return tape_stage_offset(B, max_steps, elem) + (size_t)B * max_steps * 6 * tape_slot_elems(H, L) * elem;
 }
 
 }  // namespace hode

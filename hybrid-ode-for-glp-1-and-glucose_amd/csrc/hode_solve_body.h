@@ -22,11 +22,36 @@ template <typename R> struct Eps;
 template <> struct Eps<float> { static constexpr float v = 1.1920929e-7f; };
 template <> struct Eps<double> { static constexpr double v = 2.220446049250313e-16; };
 
+// The right-hand side as a functor: F = rhs(t, Y, meal, tvns, gde, rec) evaluates f(t, x, u) in the replicated state
+// layout and, when rec != nullptr, records what the adjoint needs for this stage (layer activations + stage state) at rec.
+//   RhsRegs  : the tuned path -- every weight in registers (MlpRegs) or hidden matrices in an LDS image (MlpLds)
+//   RhsStream: the generic path (hode_generic.h) -- H <= 128, any depth, weights streamed from L2
+template <typename R, int NL, typename WT> struct RhsRegs {
+    const WT &W;
+    const OdeP<R> &o;
+    int lane;
+    static constexpr bool kKeep = true;
+    __device__ __forceinline__ int slot_elems() const { return (NL + 1) * kWave; }
+    __device__ __forceinline__ R operator()(R ts, R Ys, R meal, R tvns, R gde, R *__restrict__ rec) const
+    {
+        if (rec != nullptr) {
+            MlpActs<R, NL> ac;
+            const R F = rhs_eval<R, NL, true>(W, o, ts, Ys, meal, tvns, gde, lane, &ac);
+            R *dst = rec + lane;
+#pragma unroll
+            for (int l = 0; l < NL; ++l) dst[l * kWave] = ac.h[l];
+            dst[NL * kWave] = Ys;
+            return F;
+        }
+        return rhs_eval<R, NL, false>(W, o, ts, Ys, meal, tvns, gde, lane, nullptr);
+    }
+};
+
 // rows  [8][64] tableau coefficient rows, cvec [8] tableau nodes (LDS, shared by the workgroup)
 // ybuf  [64 + 8] output staging of THIS wave (LDS)
-// W     weights holder (MlpRegs / MlpLds), o = the 17 mechanistic constants of trajectory b's parameter set
-template <typename R, int NL, int METHOD, bool TAPE, bool GD, typename WT>
-__device__ __forceinline__ void solve_one(const SolveArgs<R> &a, const int b, const WT &W, const OdeP<R> &o,
+// rhs   the right-hand side functor of trajectory b's parameter set; o = its 17 mechanistic constants (Hill term)
+template <typename R, int METHOD, bool TAPE, bool GD, typename RHS>
+__device__ __forceinline__ void solve_one(const SolveArgs<R> &a, const int b, const RHS &rhs, const OdeP<R> &o,
                                           const R *__restrict__ rows, const R *__restrict__ cvec, R *__restrict__ ybuf,
                                           const int lane)
 {
@@ -36,8 +61,8 @@ __device__ __forceinline__ void solve_one(const SolveArgs<R> &a, const int b, co
     R *__restrict__ yb = a.y + (size_t)b * T * 6;
     R *__restrict__ tape = TAPE ? a.tape + (size_t)b * a.max_steps * 8 : nullptr;
     int *__restrict__ tseg = TAPE ? a.tape_seg + (size_t)b * a.max_steps : nullptr;
-    // stage tape: [step][stage 0..5][NL activations + stage state][64 lanes]
-    constexpr int kSlot = (NL + 1) * kWave;
+    // stage tape: [step][stage 0..5][record]; record = layer activations + stage state (rhs.slot_elems() reals)
+    const int kSlot = rhs.slot_elems();
     R *__restrict__ stg = TAPE ? a.tape_stage + (size_t)b * a.max_steps * 6 * kSlot : nullptr;
     constexpr bool use_gd = GD;               // the Hill term (two pow calls) only exists in the GD instantiation
     const TableauData &tab = kTableau[METHOD];
@@ -92,19 +117,11 @@ __device__ __forceinline__ void solve_one(const SolveArgs<R> &a, const int b, co
             const R al = (ts - t0) * inv_len;
             R gde = R(0);
             if constexpr (use_gd) gde = gd_effect(o, rfma(al, dd, d0));
+            R *rec = nullptr;
             if constexpr (TAPE) {
-                MlpActs<R, NL> ac;
-                const R F = rhs_eval<R, NL, true>(W, o, ts, Ys, rfma(al, dm, m0), rfma(al, dv, v0), gde, lane, &ac);
-                if (slot >= 0 && slot < a.max_steps * 6) {
-                    R *dst = stg + (size_t)slot * kSlot + lane;
-#pragma unroll
-                    for (int l = 0; l < NL; ++l) dst[l * kWave] = ac.h[l];
-                    dst[NL * kWave] = Ys;
-                }
-                return F;
-            } else {
-                return rhs_eval<R, NL, false>(W, o, ts, Ys, rfma(al, dm, m0), rfma(al, dv, v0), gde, lane, nullptr);
+                if (slot >= 0 && slot < a.max_steps * 6) rec = stg + (size_t)slot * kSlot;
             }
+            return rhs(ts, Ys, rfma(al, dm, m0), rfma(al, dv, v0), gde, rec);
         };
         // `closes`: the step ends exactly on the grid point t1 (bit 30 of the interval index; the adjoint needs it to know
         // which grid rows a FAILED trajectory still wrote)

@@ -28,7 +28,8 @@ __global__ __launch_bounds__(64, LB) void solve_fwd_kernel(const SolveArgs<R> a)
     OdeP<R> o;
     ode_load(o, a.ode_p + 17 * set);
     __syncthreads();
-    solve_one<R, NL, METHOD, TAPE, GD>(a, b, W, o, rows, cvec, ybuf, lane);
+    const RhsRegs<R, NL, MlpRegs<R, NL>> rhs{W, o, lane};
+    solve_one<R, METHOD, TAPE, GD>(a, b, rhs, o, rows, cvec, ybuf, lane);
 }
 
 template <typename R, int NL, int METHOD, bool TAPE, bool GD>

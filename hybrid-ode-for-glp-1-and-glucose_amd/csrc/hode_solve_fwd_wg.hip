@@ -44,7 +44,8 @@ __global__ __launch_bounds__(64 * WPB, (WPB >= 4) ? WPB / 4 : 1) void solve_fwd_
     W.load_regs();
     // no workgroup barrier below this line: the waves of a workgroup integrate independent trajectories
     const int bi = blockIdx.x * WPB + wave;
-    if (bi < per_set) solve_one<float, NL, METHOD, TAPE, GD>(a, set * per_set + bi, W, o, rows, cvec, ybuf, lane);
+    const RhsRegs<float, NL, MlpLds<NL, NREG>> rhs{W, o, lane};
+    if (bi < per_set) solve_one<float, METHOD, TAPE, GD>(a, set * per_set + bi, rhs, o, rows, cvec, ybuf, lane);
 }
 
 template <int NL> constexpr size_t fwd_wg_lds_bytes(int wpb)

@@ -17,7 +17,7 @@ _ERR = {-1: "HODE_EINVAL (bad argument)", -2: "HODE_EUNSUPPORTED (shape outside 
         -3: "HODE_ELAUNCH (HIP launch failed)"}
 
 # every symbol include/hode.h declares (tests check that the library exports all of them)
-SYMBOLS = ["hode_version", "hode_nn_param_count", "hode_tape_bytes", "hode_rhs_fwd_f32", "hode_rhs_fwd_f64",
+SYMBOLS = ["hode_version", "hode_nn_param_count", "hode_tape_bytes", "hode_tape_bytes_hl", "hode_rhs_fwd_f32", "hode_rhs_fwd_f64",
            "hode_rhs_bwd_f32", "hode_rhs_bwd_f64", "hode_solve_fwd_f32", "hode_solve_fwd_f64",
            "hode_solve_bwd_f32", "hode_solve_bwd_f64", "hode_adam_step_f32", "hode_mse_fwd_bwd_f32",
            "hode_selftest_xlane", "hode_4gi_default_params", "hode_4gi_generate_f64", "hode_4gi_rhs_f64",
@@ -43,6 +43,8 @@ def load():
         _lib.hode_version.restype = C.c_char_p
         _lib.hode_tape_bytes.restype = C.c_size_t
         _lib.hode_tape_bytes.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
+        _lib.hode_tape_bytes_hl.restype = C.c_size_t
+        _lib.hode_tape_bytes_hl.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
     return _lib
 
 
@@ -123,8 +125,8 @@ class Solve:
     __slots__ = ("y", "status", "nsteps", "nfev", "tape", "max_steps", "ctx")
 
 
-def tape_nbytes(B, max_steps, elem_size, L):
-    return load().hode_tape_bytes(B, max_steps, elem_size, L)
+def tape_nbytes(B, max_steps, elem_size, L, H=64):
+    return load().hode_tape_bytes_hl(B, max_steps, elem_size, H, L)
 
 
 def solve_fwd(x0, t, meal, tvns, gd, ode_p, nn_p, H, L, method=METHOD_DP54, rtol=1e-6, atol=1e-8,
@@ -162,7 +164,7 @@ def solve_fwd(x0, t, meal, tvns, gd, ode_p, nn_p, H, L, method=METHOD_DP54, rtol
     s.max_steps = max_steps
     s.tape = None
     if want_tape or tape is not None:
-        nbytes = load().hode_tape_bytes(B, max_steps, x0.element_size(), L)
+        nbytes = load().hode_tape_bytes_hl(B, max_steps, x0.element_size(), H, L)
         if tape is not None:
             if tape.dtype != torch.uint8 or not tape.is_cuda or tape.numel() < nbytes or tape.data_ptr() % 256:
                 raise HodeError(f"tape buffer must be a 256-byte aligned uint8 device tensor of >= {nbytes} bytes")

@@ -163,7 +163,7 @@ class _SolveFn(torch.autograd.Function):
         need_tape = any(ctx.needs_input_grad[:3])
         B, T = x0.shape[0], t.shape[-1]
         steps = _tape_steps(T, method, tape_steps)
-        per_traj = hode.capi.tape_nbytes(1, steps, x0.element_size(), L)
+        per_traj = hode.capi.tape_nbytes(1, steps, x0.element_size(), L, H)
         budget = _tape_budget(x0.device) if need_tape else 0
         ctx.chunked = need_tape and B * per_traj > budget
         ctx.sol = None
@@ -257,7 +257,7 @@ class _GaussLikFn(torch.autograd.Function):
         B, T = x0.shape[0], t.shape[-1]
         P = nn_flat.numel() // S
         steps = _tape_steps(T, method, tape_steps)
-        cap = max(1, _tape_budget(x0.device) // hode.capi.tape_nbytes(1, steps, x0.element_size(), L)) if grads else S * B
+        cap = max(1, _tape_budget(x0.device) // hode.capi.tape_nbytes(1, steps, x0.element_size(), L, H)) if grads else S * B
         ss = torch.zeros(1, dtype=torch.float64, device=x0.device)
         gx0 = torch.zeros_like(x0) if need[0] else None
         gnn = torch.zeros_like(nn_flat) if need[1] else None
@@ -364,8 +364,8 @@ class HybridODENN(nn.Module):
     # ------------------------------------------------------------------ plumbing
     def _check_supported(self):
         if not self.nn_residual.hip_supported():
-            raise NotImplementedError("HIP kernels are compiled for a ReLU MLP 9 -> (<=64) x (1..4) -> 6 without "
-                                      "dropout; other NNResidual configurations are outside the hot path")
+            raise NotImplementedError("the HIP path computes a ReLU MLP 9 -> (<=128) x (1..8) -> 6 without dropout "
+                                      "(include/hode.h); other NNResidual configurations are outside the hot path")
 
     def _params_on(self, dev, params: Optional[Dict[str, torch.Tensor]] = None):
         """(nn_flat, ode_vec) on the compute device; `params` optionally overrides named entries

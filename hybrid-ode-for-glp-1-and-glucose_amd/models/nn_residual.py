@@ -45,9 +45,10 @@ class NNResidual(nn.Module):
 
     # ---- what the HIP kernels consume -----------------------------------------------------
     def hip_supported(self) -> bool:
-        """The kernels are compiled for ReLU, input 9, output 6, hidden <= 64, 1..4 hidden layers."""
+        """include/hode.h: ReLU, no dropout, input 9, output 6, hidden <= 128, 1..8 hidden layers (register-resident kernels up
+        to 64 x 4, generic streamed-weight kernels beyond)."""
         return (self.activation_name == "relu" and self.dropout == 0 and self.input_dim == 9
-                and self.output_dim == 6 and 1 <= self.hidden_dim <= 64 and 1 <= self.n_layers <= 4)
+                and self.output_dim == 6 and 1 <= self.hidden_dim <= 128 and 1 <= self.n_layers <= 8)
 
     def flat_parameters(self) -> torch.Tensor:
         """W1,b1,...,Wout,bout concatenated in parameters() order (differentiable cat)."""

@@ -50,19 +50,31 @@ extern "C" {
 #define HODE_ST_UNDERFLOW 2 /* step size below 10 ulp(t) (scipy rk.py:128-129) */
 #define HODE_ST_NONFINITE 3 /* state became non-finite */
 
-#define HODE_MAX_HIDDEN 64 /* MLP width compiled for (one hidden unit per wavefront lane) */
-#define HODE_MAX_LAYERS 4  /* hidden layers compiled for */
+/* Network envelope.  NNResidual (models/nn_residual.py:28-98) builds 9 -> H x L -> 6 for any H, L; the reference's configs
+ * use 64 x 4 (default, 4gi_*, mimic_clinical) and 128 x 5 (configs/ablation_no_physics.yaml:11-12).
+ *   H <= 64 and L <= 4   tuned kernels: all weights register-resident, one hidden unit per wavefront lane;
+ *   otherwise            generic kernels (two hidden units per lane, weights streamed from L2, gradients by coalesced
+ *                        atomics), same results contract, sized for the batches such shapes are trained with.
+ * Activation: ReLU, no dropout.  NNResidual also offers tanh / elu / leaky_relu(0.1) and dropout, but HybridODENN
+ * (models/hybrid_ode_nn.py:55-60) never passes either, so no caller of this path can select them: the host class raises
+ * NotImplementedError for them instead of silently computing something else. */
+#define HODE_MAX_HIDDEN 128
+#define HODE_MAX_LAYERS 8
+#define HODE_TUNED_HIDDEN 64 /* envelope of the register-resident kernels */
+#define HODE_TUNED_LAYERS 4
 
 const char *hode_version(void);
 
-/* number of MLP parameters for (H hidden, L hidden layers); 13510 for (64,4) */
+/* number of MLP parameters for (H hidden, L hidden layers); 13510 for (64,4), 68102 for (128,5) */
 int hode_nn_param_count(int H, int L);
 
 /* bytes of the tape the solve writes for the adjoint: per accepted step {t, h, y[6]}, the grid
- * interval, and the "stage tape" -- the MLP activations and stage state of every Runge-Kutta stage
- * (6 x (L+1) x 64 reals per step), so that the adjoint never recomputes the forward.  This is a
- * memory-for-compute trade sized for 288 GB of HBM: 7.7 KB per step in fp32 for L = 4, i.e.
- * 2.3 MB per trajectory at max_steps = 300. */
+ * interval (bit 30 set when the step ended exactly on the grid point closing that interval), and the "stage tape" -- the
+ * MLP activations and stage state of every Runge-Kutta stage (6 x (L+1) x 64 reals per step on the tuned path,
+ * 6 x (2L+1) x 64 on the generic one), so that the adjoint never recomputes the forward.  This is a
+ * memory-for-compute trade sized for 288 GB of HBM: 7.7 KB per step in fp32 for (64,4), i.e.
+ * 2.3 MB per trajectory at max_steps = 300.  hode_tape_bytes(.., L) == hode_tape_bytes_hl(.., 64, L). */
+size_t hode_tape_bytes_hl(int B, int max_steps, int elem_size /* 4 or 8 */, int H, int L);
 size_t hode_tape_bytes(int B, int max_steps, int elem_size /* 4 or 8 */, int L);
 
 /* ---- K1: RHS forward.  Replaces HybridODENN.ode_residual (models/hybrid_ode_nn.py:108-134)
@@ -90,7 +102,7 @@ int hode_rhs_bwd_f64(void *stream, int B, const double *x, const double *t, cons
  *      (:210-231) and the RK45 stepper (scipy/integrate/_ivp/rk.py:14-72,111-176).
  *      t: [T] (t_batched=0) or [B,T] (t_batched=1).  y[B,T,6] written (rows after a failure
  *      are zero).  status/nsteps/nfev: int32[B] (nsteps/nfev may be NULL).
- *      tape: NULL, or hode_tape_bytes(B,max_steps,sizeof(real),L) bytes (256-byte aligned) that
+ *      tape: NULL, or hode_tape_bytes_hl(B,max_steps,sizeof(real),H,L) bytes (256-byte aligned) that
  *      receive the accepted steps and their stage activations (needed by hode_solve_bwd_*).     */
 int hode_solve_fwd_f32(void *stream, int B, int T, const float *x0, const float *t, int t_batched,
                        const float *meal, int meal_mode, const float *tvns, int tvns_mode,

@@ -1,0 +1,179 @@
+"""The generic network path (csrc/hode_generic.hip): MLP shapes outside the register-resident envelope, up to 8 x 128 --
+in particular the reference's largest config, nn_hidden 128 / nn_layers 5 (configs/ablation_no_physics.yaml:11-12) --
+against the oracle (HODE_MAXH 128, HODE_MAXL 8): K1, K5, K2+K3 and K4, fp32 and fp64, through the C ABI and the class."""
+import os
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from oracle import oracle as O  # noqa: E402  (checker only)
+
+SHAPES = [(128, 5), (96, 6), (64, 5), (100, 2), (128, 8), (7, 5)]
+
+
+def rel(a, b, floor=1e-3):
+    return float(np.max(np.abs(np.asarray(a, np.float64) - b) / (np.abs(b) + floor)))
+
+
+def relnorm(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-300))
+
+
+def dev(a, dtype):
+    return None if a is None else torch.as_tensor(np.asarray(a), dtype=dtype, device="cuda")
+
+
+@pytest.fixture(scope="module")
+def hode():
+    import hode as h
+    h.load()
+    return h
+
+
+def net(H, L, seed=0):
+    """xavier-like hidden layers (gain 0.5 so that ReLU units live and die), small non-zero output layer."""
+    rng = np.random.default_rng(seed + 1000 * H + L)
+    parts = []
+    dims = [(H, 9)] + [(H, H)] * (L - 1) + [(6, H)]
+    for i, (o, n) in enumerate(dims):
+        std = 0.02 if i == len(dims) - 1 else 0.5 * (2.0 / (o + n)) ** 0.5
+        parts += [rng.standard_normal((o, n)) * std, rng.standard_normal(o) * (0.01 if i == len(dims) - 1 else 0.05)]
+    p = np.concatenate([a.reshape(-1) for a in parts]).astype(np.float32).astype(np.float64)
+    assert p.size == O.n_params(H, L)
+    return p
+
+
+def cohort(golden_dir, B=6):
+    g = np.load(os.path.join(golden_dir, "g4_t61_pulses.npz"))
+    sel = np.arange(0, 61, 4)
+    return g["x0"][:B].astype(np.float64), g["t"][sel].astype(np.float64), g["meal"][:B, sel].astype(np.float64), g["tvns"][:B, sel].astype(np.float64)
+
+
+@pytest.mark.parametrize("H,L", SHAPES)
+def test_rhs_fwd_bwd_generic_vs_oracle(hode, golden_dir, g0, H, L):
+    r = np.load(os.path.join(golden_dir, "g123_rhs.npz"))
+    x, t, meal, tv, gd = (r[k].astype(np.float64) for k in ("x", "t", "meal", "tvns", "gd"))
+    nn, ode = net(H, L), g0["ode"].astype(np.float64)
+    w = np.random.default_rng(1).standard_normal(x.shape)
+    for dt, tol_f, tol_g in ((torch.float64, 1e-12, 1e-10), (torch.float32, 5e-6, 3e-5)):
+        npdt = np.float64 if dt == torch.float64 else np.float32
+        want = O.rhs(x, t, meal, tv, gd, ode, nn, H, L, dtype=np.float64)
+        got = hode.rhs_fwd(dev(x, dt), dev(t, dt), dev(meal, dt), dev(tv, dt), dev(gd, dt), dev(ode, dt), dev(nn, dt), H, L)
+        assert rel(got.cpu().numpy(), want) < tol_f, (H, L, dt)
+        rgx, rgnn, rgode = O.rhs_vjp(x, t, meal, tv, gd, ode, nn, H, L, w, dtype=np.float64)
+        e = 1e-6                                                # d/dt by central differences of the oracle (t only enters the MLP)
+        rgt = ((O.rhs(x, t + e, meal, tv, gd, ode, nn, H, L, dtype=np.float64) - O.rhs(x, t - e, meal, tv, gd, ode, nn, H, L, dtype=np.float64))
+               / (2 * e) * w).sum(1)
+        gx, gt, gnn, gode = hode.rhs_bwd(dev(x, dt), dev(t, dt), dev(meal, dt), dev(tv, dt), dev(gd, dt), dev(ode, dt), dev(nn, dt), H, L,
+                                         dev(w, dt), want_gt=True, want_gnn=True, want_gode=True)
+        assert relnorm(gx.cpu().numpy(), rgx) < tol_g and relnorm(gnn.cpu().numpy(), rgnn) < tol_g, (H, L, npdt)
+        assert relnorm(gt.cpu().numpy(), rgt) < max(10 * tol_g, 1e-6) and relnorm(gode.cpu().numpy(), rgode) < 10 * tol_g
+
+
+@pytest.mark.parametrize("H,L", SHAPES)
+def test_solve_and_adjoint_generic_fp64_vs_oracle(hode, golden_dir, g0, H, L):
+    x0, t, meal, tv = cohort(golden_dir)
+    nn, ode = net(H, L), g0["ode"].astype(np.float64)
+    c = np.random.default_rng(2).standard_normal((x0.shape[0], len(t), 6))
+    dt = torch.float64
+    for method in (O.METHOD_DP54, O.METHOD_RK4):
+        ref = O.solve(x0, t, meal, tv, None, ode, nn, H, L, method=method, rtol=1e-8, atol=1e-10, dtype=np.float64, want_tape=True)
+        s = hode.solve_fwd(dev(x0, dt), dev(t, dt), dev(meal, dt), dev(tv, dt), None, dev(ode, dt), dev(nn, dt), H, L, method=method,
+                           rtol=1e-8, atol=1e-10, want_tape=True)
+        assert int(s.status.max()) == 0 and np.array_equal(s.nsteps.cpu().numpy(), ref.nsteps), (H, L, method)
+        assert np.array_equal(s.nfev.cpu().numpy(), ref.nfev) and rel(s.y.cpu().numpy(), ref.y) < 1e-9
+        rx, rnn, rode = O.solve_bwd(ref, c)
+        gx0, gnn, gode = hode.solve_bwd(s, dev(c, dt), want_gode=True)
+        assert relnorm(gx0.cpu().numpy(), rx) < 1e-8 and relnorm(gnn.cpu().numpy(), rnn) < 1e-8, (H, L, method)
+        assert relnorm(gode.cpu().numpy(), rode) < 1e-7
+        # without a tape: same trajectories
+        s2 = hode.solve_fwd(dev(x0, dt), dev(t, dt), dev(meal, dt), dev(tv, dt), None, dev(ode, dt), dev(nn, dt), H, L, method=method,
+                            rtol=1e-8, atol=1e-10)
+        assert torch.equal(s2.y, s.y)
+
+
+def test_reference_ablation_shape_fp32_forward_adjoint_and_sets(hode, golden_dir, g0):
+    """nn_hidden 128, nn_layers 5 at the reference's batch (32 windows of 61 points): fp32 at the default tolerances against
+    the fp64 oracle at tight ones (bars 1e-3 / 1e-4), two parameter sets, batched time grid, failure -> status."""
+    H, L = 128, 5
+    g = np.load(os.path.join(golden_dir, "g4_t61_pulses.npz"))
+    x0 = np.concatenate([g["x0"]] * 4) * (1 + 0.01 * np.arange(32)[:, None])
+    meal, tv = np.concatenate([g["meal"]] * 4), np.concatenate([g["tvns"]] * 4)
+    t = g["t"].astype(np.float64)
+    nn, ode = net(H, L), g0["ode"].astype(np.float64)
+    f32 = torch.float32
+    s = hode.solve_fwd(dev(x0, f32), dev(t, f32), dev(meal, f32), dev(tv, f32), None, dev(ode, f32), dev(nn, f32), H, L, want_tape=True)
+    ref = O.solve(x0, t, meal, tv, None, ode, nn, H, L, rtol=1e-10, atol=1e-12, dtype=np.float64, want_tape=True)
+    assert int(s.status.max()) == 0 and rel(s.y.cpu().numpy(), ref.y) < 1e-4
+    bare = O.solve(x0[:4], t, meal[:4], tv[:4], None, ode, np.zeros_like(nn), H, L, rtol=1e-8, atol=1e-10, dtype=np.float64)
+    assert rel(bare.y, ref.y[:4]) > 1e-2                                  # the network matters in this test
+    c = np.random.default_rng(3).standard_normal(ref.y.shape)
+    _, rnn, _ = O.solve_bwd(ref, c)
+    gx0, gnn, _ = hode.solve_bwd(s, dev(c, f32))
+    assert relnorm(gnn.cpu().numpy(), rnn) < 1e-4
+    # two parameter sets x 16 patients, batched time grid
+    nn2 = np.concatenate([nn, 0.5 * nn])
+    tb = np.tile(t, (32, 1)) * (1 + 0.01 * np.arange(32)[:, None])
+    dt = torch.float64
+    s2 = hode.solve_fwd(dev(x0, dt), dev(tb, dt), dev(meal, dt), dev(tv, dt), None, dev(np.concatenate([ode, ode]), dt), dev(nn2, dt), H, L,
+                        n_sets=2, rtol=1e-8, atol=1e-10, want_tape=True)
+    gx2, gnn2, _ = hode.solve_bwd(s2, dev(c, dt))
+    P = nn.size
+    for k, (p_k, sl) in enumerate(((nn, slice(0, 16)), (0.5 * nn, slice(16, 32)))):
+        r_k = O.solve(x0[sl], tb[sl], meal[sl], tv[sl], None, ode, p_k, H, L, rtol=1e-8, atol=1e-10, dtype=np.float64, want_tape=True)
+        assert rel(s2.y[sl].cpu().numpy(), r_k.y) < 1e-9
+        rx_k, rnn_k, _ = O.solve_bwd(r_k, c[sl])
+        assert relnorm(gnn2[k * P:(k + 1) * P].cpu().numpy(), rnn_k) < 1e-8 and relnorm(gx2[sl].cpu().numpy(), rx_k) < 1e-8
+    # step budget exhausted -> status 1, zero rows, finite gradients of what was written
+    s3 = hode.solve_fwd(dev(x0[:3], dt), dev(t, dt), dev(meal[:3], dt), dev(tv[:3], dt), None, dev(ode, dt), dev(nn, dt), H, L,
+                        rtol=1e-8, atol=1e-10, want_tape=True, max_steps=20)
+    r3 = O.solve(x0[:3], t, meal[:3], tv[:3], None, ode, nn, H, L, rtol=1e-8, atol=1e-10, dtype=np.float64, want_tape=True, max_steps=20)
+    assert (s3.status.cpu().numpy() == 1).all() and rel(s3.y.cpu().numpy(), r3.y) < 1e-9
+    g3x, g3n, _ = hode.solve_bwd(s3, dev(c[:3], dt))
+    r3x, r3n, _ = O.solve_bwd(r3, c[:3])
+    assert relnorm(g3x.cpu().numpy(), r3x) < 1e-8 and relnorm(g3n.cpu().numpy(), r3n) < 1e-8
+
+
+def test_class_surface_with_the_ablation_network():
+    """HybridODENN(nn_hidden=128, nn_layers=5) -- what train_hybrid.py builds from configs/ablation_no_physics.yaml -- runs
+    forward / loss / backward / an Adam step on the HIP path, and its ode_residual equals the torch modules."""
+    import models
+    torch.manual_seed(0)
+    m = models.HybridODENN(nn_hidden=128, nn_layers=5, device="cuda")
+    with torch.no_grad():
+        m.nn_residual.network[-1].weight.normal_(0, 0.01)
+    assert sum(p.numel() for p in m.nn_residual.parameters()) == 68102
+    B, T = 32, 61
+    g = torch.Generator().manual_seed(1)
+    x0 = (torch.tensor([5.0, 60.0, 80.0, 10.0, 0.0, 1.0]) * (1 + 0.05 * torch.randn(B, 6, generator=g))).cuda()
+    t = torch.linspace(0, 5, T).cuda()
+    meal = torch.zeros(B, T)
+    meal[:, 6] = meal[:, 30] = 1.0
+    u = {"meal": meal.cuda(), "tVNS": torch.zeros(B, T).cuda()}
+    with torch.no_grad():
+        y = m.forward(x0, t, u)
+        f = m.ode_residual(t[3], x0, {"meal": u["meal"][:, 3], "tVNS": u["tVNS"][:, 3]})
+        eager = m.ode_core(t[3], x0, {"meal": u["meal"][:, 3]}) + m.nn_residual(t[3], x0, x0[:, 3], u["tVNS"][:, 3])
+    assert y.shape == (B, T, 6) and m.solve_failures() == 0
+    assert rel(f.cpu().numpy(), eager.double().cpu().numpy()) < 5e-6
+    batch = {"initial_state": x0, "observations": y + 0.05 * torch.randn(y.shape, device="cuda"), "time_points": t, "external_inputs": u}
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    before = [p.detach().clone() for p in m.nn_residual.parameters()]
+    losses = []
+    for _ in range(3):
+        opt.zero_grad()
+        loss = m.loss(batch, lambda1=0.0, lambda2=0.1, use_physics_loss=False)      # the ablation's settings
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(m.parameters(), 5.0)
+        opt.step()
+        losses.append(float(loss))
+    assert all(np.isfinite(losses)) and all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.nn_residual.parameters())
+    assert all(float((a - b).abs().max()) > 0 for a, b in zip(before, m.nn_residual.parameters()))
+    # the physics-loss route (K1 + K5 under autograd) works for this shape too
+    opt.zero_grad()
+    m.loss(batch, lambda1=1.0, lambda2=0.1).backward()
+    assert float(m.nn_residual.network[0].weight.grad.abs().max()) > 0

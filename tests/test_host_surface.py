@@ -36,6 +36,10 @@ def test_library_exports_every_declared_symbol():
     assert hode.version().startswith("hode ")
     assert lib.hode_nn_param_count(64, 4) == 13510 and lib.hode_nn_param_count(32, 2) == 1574
     assert hode.load().hode_tape_bytes(4096, 300, 4, 4) == 4096 * 300 * 36 + 4096 * 300 * 6 * 5 * 64 * 4
+    # the generic path (H > 64 or L > 4) records two rows of 64 per layer: (2L + 1) x 64 reals per stage
+    assert lib.hode_tape_bytes_hl(32, 92, 4, 128, 5) == 32 * 92 * 36 + 32 * 92 * 6 * 11 * 64 * 4
+    assert lib.hode_tape_bytes_hl(32, 92, 4, 64, 4) == lib.hode_tape_bytes(32, 92, 4, 4)
+    assert lib.hode_nn_param_count(128, 5) == 68102 and lib.hode_tape_bytes_hl(1, 1, 4, 129, 5) == 0
 
 
 def test_argument_validation_without_gpu():
@@ -45,8 +49,10 @@ def test_argument_validation_without_gpu():
     assert lib.hode_solve_fwd_f32(z, 4, 10, z, z, 0, z, 0, z, 0, z, 0, z, z, 1, 64, 4, 0, ctypes.c_double(1e-6),
                                   ctypes.c_double(1e-8), 100, z, z, z, z, z) == -1          # null pointers
     one = ctypes.c_void_p(16)
-    assert lib.hode_solve_fwd_f32(z, 4, 10, one, one, 0, z, 0, z, 0, z, 0, one, one, 1, 128, 4, 0,
-                                  ctypes.c_double(1e-6), ctypes.c_double(1e-8), 100, one, one, z, z, z) == -2  # H > 64
+    assert lib.hode_solve_fwd_f32(z, 4, 10, one, one, 0, z, 0, z, 0, z, 0, one, one, 1, 129, 4, 0,
+                                  ctypes.c_double(1e-6), ctypes.c_double(1e-8), 100, one, one, z, z, z) == -2  # H > 128
+    assert lib.hode_solve_fwd_f32(z, 4, 10, one, one, 0, z, 0, z, 0, z, 0, one, one, 1, 64, 9, 0,
+                                  ctypes.c_double(1e-6), ctypes.c_double(1e-8), 100, one, one, z, z, z) == -2  # L > 8
     assert lib.hode_solve_fwd_f32(z, 4, 10, one, one, 0, z, 0, z, 0, z, 0, one, one, 3, 64, 4, 0,
                                   ctypes.c_double(1e-6), ctypes.c_double(1e-8), 100, one, one, z, z, z) == -1  # B % n_sets
     assert lib.hode_solve_fwd_f32(z, 4, 10, one, one, 0, z, 2, z, 0, z, 0, one, one, 1, 64, 4, 0,
