@@ -13,7 +13,7 @@ METHOD_DP54 = 0
 METHOD_RK4 = 1
 
 ST_OK, ST_MAXSTEPS, ST_UNDERFLOW, ST_NONFINITE = 0, 1, 2, 3
-_ERR = {-1: "HODE_EINVAL (bad argument)", -2: "HODE_EUNSUPPORTED (shape outside compiled range: H<=64, L<=4)",
+_ERR = {-1: "HODE_EINVAL (bad argument)", -2: "HODE_EUNSUPPORTED (shape outside the supported range: H<=128, L<=8)",
         -3: "HODE_ELAUNCH (HIP launch failed)"}
 
 # every symbol include/hode.h declares (tests check that the library exports all of them)
