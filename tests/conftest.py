@@ -24,7 +24,7 @@ def pytest_configure(config):
 # GPU suite order (the driver runs `pytest -x -m gpu`): the hot path first -- one test per BASELINE.json config
 # (test_cfg1..5), then the kernel parity file, the class surface, the plain-C program -- and the "next" rows (data side)
 # last, so a failure in a widening row can never hide the evidence for SURVEY section 8's (a) rows.
-_FILE_ORDER = ["test_hip_parity.py", "test_models_gpu.py", "test_vi_gpu.py", "test_c_example.py", "test_bench_contract_gpu.py",
+_FILE_ORDER = ["test_hip_parity.py", "test_models_gpu.py", "test_generic_gpu.py", "test_vi_gpu.py", "test_c_example.py", "test_bench_contract_gpu.py",
                "test_data_side_gpu.py"]
 
 

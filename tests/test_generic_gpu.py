@@ -71,7 +71,7 @@ def test_rhs_fwd_bwd_generic_vs_oracle(hode, golden_dir, g0, H, L):
         gx, gt, gnn, gode = hode.rhs_bwd(dev(x, dt), dev(t, dt), dev(meal, dt), dev(tv, dt), dev(gd, dt), dev(ode, dt), dev(nn, dt), H, L,
                                          dev(w, dt), want_gt=True, want_gnn=True, want_gode=True)
         assert relnorm(gx.cpu().numpy(), rgx) < tol_g and relnorm(gnn.cpu().numpy(), rgnn) < tol_g, (H, L, npdt)
-        assert relnorm(gt.cpu().numpy(), rgt) < max(10 * tol_g, 1e-6) and relnorm(gode.cpu().numpy(), rgode) < 10 * tol_g
+        assert relnorm(gt.cpu().numpy(), rgt) < 1e-4 and relnorm(gode.cpu().numpy(), rgode) < 10 * tol_g
 
 
 @pytest.mark.parametrize("H,L", SHAPES)
