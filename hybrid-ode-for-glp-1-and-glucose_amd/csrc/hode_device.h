@@ -813,9 +813,10 @@ __device__ __forceinline__ void edge_table_store(R *__restrict__ tab, const R *_
         R v = R(0);
         if (j < H) {
             if (slot < S::b) v = p[j * 9 + slot];
+            else if (slot == S::b) v = p[9 * H + j];                     // b_1: the VJP recomputes h_1
             else if (slot >= S::w5 && slot < S::b5) v = pout[(slot - S::w5) * H + j];
         }
-        tab[i] = v;            // bias slots hold no weight the VJP needs
+        tab[i] = v;            // the other bias slots hold no weight the VJP needs
     }
 }
 // flush the edge accumulators into the flat gradient vector
@@ -915,22 +916,36 @@ __device__ __forceinline__ R mech_vjp(const OdeP<R> &o, R G, R I, R Glu, R GLP1,
 // same layout and accumulates parameter gradients.  acts = activations of this evaluation (from
 // rhs_eval<KEEP> or from the stage tape).  Needs only the first/last layer weights in registers;
 // the hidden matrices come transposed from LDS (wt).   GODE: also d/d(ode constants) (wave-uniform values).
+//   x[6]  the stage state as six wave-uniform values (scalar loads from the compact stage record / the input batch)
+//   acts  h_2 .. h_NL of this evaluation in acts.h[1 .. NL-1]; h_1 = acts.h[0] is NOT read: it is recomputed here from
+//         (t, x, tvns) with the first-layer weights of the edge table (9 FMAs instead of a 256-byte tape row per stage)
 template <typename R, int NL, bool GODE, bool GT, typename Edge, typename Wt>
 __device__ __forceinline__ R rhs_vjp(Edge &e, R (&gwh)[(NL > 1) ? NL - 1 : 1][kMaxH], const Wt &wt,
-                                     const OdeP<R> &o, R t, R Y, R tvns, R gde, R gd_in, bool use_gd, int lane,
+                                     const OdeP<R> &o, R t, const R (&x)[6], R tvns, R gde, R gd_in, bool use_gd, int lane,
                                      const MlpActs<R, NL> &acts, R kb, R &go, R *gt_out)
 {
     using S = EdgeSlots<NL>;
     // increments of the edge-parameter gradients are collected and applied in ONE batch at the end
     R inc[S::count];
-    const R G = lane_bcast(Y, 0), I = lane_bcast(Y, 1), Glu = lane_bcast(Y, 2), GLP1 = lane_bcast(Y, 3),
-            GE = lane_bcast(Y, 4), FFA = lane_bcast(Y, 5);
+    const R G = x[0], I = x[1], Glu = x[2], GLP1 = x[3], GE = x[4], FFA = x[5];
+    // h_1 exactly as rhs_eval computes it (same operation order)
+    R h1 = e.W(S::b + 0);
+    h1 = rfma(e.W(S::w1 + 0), t, h1);
+    h1 = rfma(e.W(S::w1 + 1), G, h1);
+    h1 = rfma(e.W(S::w1 + 2), I, h1);
+    h1 = rfma(e.W(S::w1 + 3), Glu, h1);
+    h1 = rfma(e.W(S::w1 + 4), GLP1, h1);
+    h1 = rfma(e.W(S::w1 + 5), GE, h1);
+    h1 = rfma(e.W(S::w1 + 6), FFA, h1);
+    h1 = rfma(e.W(S::w1 + 7), GLP1, h1);
+    h1 = rfma(e.W(S::w1 + 8), tvns, h1);
+    h1 = rmax0(h1);
     const R lG = lane_bcast(kb, 0), lI = lane_bcast(kb, 1), lGlu = lane_bcast(kb, 2), lGLP = lane_bcast(kb, 3),
             lGE = lane_bcast(kb, 4), lF = lane_bcast(kb, 5);
     const int c8 = lane & 7;
     const R mech = mech_vjp<R, GODE>(o, G, I, Glu, GLP1, FFA, lG, lI, lGlu, lGLP, lF, gde, gd_in, use_gd, lane, go);
     // ---- MLP backward
-    const R hl = acts.h[NL - 1];
+    const R hl = (NL > 1) ? acts.h[NL - 1] : h1;
     // fetch the six output-layer weights in one batch (LDS policy: six reads in flight, one wait)
     const R w50 = e.W(S::w5 + 0), w51 = e.W(S::w5 + 1), w52 = e.W(S::w5 + 2), w53 = e.W(S::w5 + 3),
             w54 = e.W(S::w5 + 4), w55 = e.W(S::w5 + 5);
@@ -950,7 +965,7 @@ __device__ __forceinline__ R rhs_vjp(Edge &e, R (&gwh)[(NL > 1) ? NL - 1 : 1][kM
     d = (hl > R(0)) ? d : R(0);
 #pragma unroll
     for (int l = NL - 1; l >= 1; --l) {           // hidden matrix l-1 maps acts.h[l-1] -> acts.h[l]
-        const R hin = acts.h[l - 1];
+        const R hin = (l > 1) ? acts.h[l - 1] : h1;
         inc[S::b + l] = d;
         const R dp = layer_bwd(gwh[l - 1], wt, l - 1, lane, d, hin);   // dW_l += d (x) h_{l-1};  dp = W_l^T d
         d = (hin > R(0)) ? dp : R(0);

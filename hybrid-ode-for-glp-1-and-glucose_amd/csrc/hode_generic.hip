@@ -11,7 +11,7 @@
 //     W[j][k] and W[j][k + 64] -- 256 contiguous bytes per wave load;
 //   * parameter gradients leave through coalesced global atomics (dW[j][:] += delta_j * h[:], one 256-byte atomic
 //     wave-instruction per matrix row and half), skipped when delta_j is exactly zero (ReLU);
-//   * depth is a run-time loop, layer activations go straight to the stage tape ((2 L + 1) rows of 64 per stage).
+//   * depth is a run-time loop, layer activations go straight to the stage tape (2 L rows of 64 + the state in 8 reals per stage).
 // It is built for the batches the reference trains such shapes with (32 patients x 61 grid points): the adjoint moves
 // ~280 KB of atomics per stage, which at the chip's ~1.3 TB/s of float atomics is 2-3 ms for that batch and grows
 // linearly with B x T.  The integrator, controller, tape format and state layout are those of the tuned path
@@ -39,7 +39,7 @@ __device__ __forceinline__ double bcast_dyn(double v, int k) { return lane_bcast
 // activation k of a layer whose units live two per lane (k < 64: register a of lane k; else register b of lane k - 64)
 template <typename R> __device__ __forceinline__ R unit_bcast(R a, R b, int k) { return k < 64 ? bcast_dyn(a, k) : bcast_dyn(b, k - 64); }
 
-// f(t, x, u) for an arbitrary network.  rec != nullptr: record h_1..h_L (two rows of 64 each) and the stage state.
+// f(t, x, u) for an arbitrary network.  rec != nullptr: record h_1..h_L (two rows of 64 each) and the stage state (8 reals).
 template <typename R>
 __device__ __forceinline__ R rhs_stream(const StreamNet<R> &n, const OdeP<R> &o, R t, R Y, R meal, R tvns, R gde, int lane,
                                         R *__restrict__ rec)
@@ -83,7 +83,7 @@ __device__ __forceinline__ R rhs_stream(const StreamNet<R> &n, const OdeP<R> &o,
 #pragma unroll
     for (int q = 0; q < 6; ++q) p[q] = n.Wo()[q * H + jA] * hA + n.Wo()[q * H + jB] * hB;     // h is 0 on masked lanes
     const R nn = wave_reduce6_to_lanes(p, lane);
-    if (rec) rec[2 * L * kWave + lane] = Y;
+    if (rec && lane < 8) rec[2 * L * kWave + lane] = Y;
     const R bout = (c8 < 6) ? n.bo()[(c8 < 6) ? c8 : 0] : R(0);
     return (c8 < 6) ? (mech + nn + bout) : R(0);
 }
@@ -92,7 +92,7 @@ template <typename R> struct RhsStream {
     StreamNet<R> n;
     const OdeP<R> &o;
     int lane;
-    __device__ __forceinline__ int slot_elems() const { return (2 * n.L + 1) * kWave; }
+    __device__ __forceinline__ int slot_elems() const { return 2 * n.L * kWave + 8; }
     __device__ __forceinline__ R operator()(R ts, R Ys, R meal, R tvns, R gde, R *__restrict__ rec) const
     {
         return rhs_stream<R>(n, o, ts, Ys, meal, tvns, gde, lane, rec);
@@ -105,9 +105,8 @@ __device__ __forceinline__ R rhs_vjp_stream(const StreamNet<R> &n, R *__restrict
                                             bool use_gd, int lane, const R *__restrict__ rec, R kb, R &go, R *gt_out)
 {
     const int H = n.H, L = n.L;
-    const R Y = rec[2 * L * kWave + lane];
-    const R G = lane_bcast(Y, 0), I = lane_bcast(Y, 1), Glu = lane_bcast(Y, 2), GLP1 = lane_bcast(Y, 3),
-            GE = lane_bcast(Y, 4), FFA = lane_bcast(Y, 5);
+    const R *__restrict__ sx = rec + 2 * L * kWave;            // the stage state: wave-uniform loads
+    const R G = sx[0], I = sx[1], Glu = sx[2], GLP1 = sx[3], GE = sx[4], FFA = sx[5];
     const R lq[6] = {lane_bcast(kb, 0), lane_bcast(kb, 1), lane_bcast(kb, 2), lane_bcast(kb, 3), lane_bcast(kb, 4), lane_bcast(kb, 5)};
     const int c8 = lane & 7;
     const R mech = mech_vjp<R, GODE>(o, G, I, Glu, GLP1, FFA, lq[0], lq[1], lq[2], lq[3], lq[5], gde, gd_in, use_gd, lane, go);
@@ -195,7 +194,7 @@ __global__ __launch_bounds__(256) void rhs_bwd_generic_kernel(const RhsArgs<R> a
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int lane = threadIdx.x & 63;
     const int wave = first_lane((int)(threadIdx.x >> 6));
-    R *rec = reinterpret_cast<R *>(smem_raw) + (size_t)wave * (2 * L + 1) * kWave;      // this wave's record
+    R *rec = reinterpret_cast<R *>(smem_raw) + (size_t)wave * (2 * L * kWave + 8);      // this wave's record
     const StreamNet<R> n{a.nn_p, a.H, L};
     OdeP<R> o;
     ode_load(o, a.ode_p);
@@ -231,7 +230,7 @@ template <typename R> int launch_rhs_bwd_generic(hipStream_t s, const RhsArgs<R>
     int blocks = (a.B + 3) / 4;
     if (blocks > 1024) blocks = 1024;
     if (blocks < 1) return HODE_OK;
-    const size_t lds = (size_t)4 * (2 * L + 1) * kWave * sizeof(R);
+    const size_t lds = (size_t)4 * (2 * L * kWave + 8) * sizeof(R);
     if (a.gode) hipLaunchKernelGGL((rhs_bwd_generic_kernel<R, true>), dim3(blocks), dim3(256), lds, s, a, L);
     else hipLaunchKernelGGL((rhs_bwd_generic_kernel<R, false>), dim3(blocks), dim3(256), lds, s, a, L);
     return hipGetLastError() == hipSuccess ? HODE_OK : HODE_ELAUNCH;
@@ -286,7 +285,7 @@ __global__ __launch_bounds__(64) void solve_bwd_generic_kernel(const AdjArgs<R> 
     const int T = a.T;
     const TableauData &tab = kTableau[method];
     const int S = tab.S;
-    const int kSlot = (2 * L + 1) * kWave;
+    const int kSlot = 2 * L * kWave + 8;
     tableau_rowsT_store<R>(rowsT, method, lane, 64);
     __syncthreads();
     const int per_set = a.B / a.n_sets;
