@@ -690,8 +690,9 @@ template <int NL> struct WtRegs {
 // One hidden layer of the backward pass: gw += d (x) hin  and  returns W^T d.
 // Generic form: the two products one after the other.
 template <typename R, typename Wt>
-__device__ __forceinline__ R layer_bwd(R (&gw)[kMaxH], const Wt &wt, int l, int lane, R d, R hin)
+__device__ __forceinline__ R layer_bwd(R (&gw)[kMaxH], const Wt &wt, int l, int lane, R d, R hin, const R *__restrict__ hrow = nullptr)
 {
+    (void)hrow;
     mlp_outer_acc(gw, d, hin);
     return wt.mul(l, lane, d);
 }
@@ -743,11 +744,23 @@ __device__ __forceinline__ void layer_bwd_group(float (&gw)[kMaxH], const Vec4<f
     acc[3] = fmac_ror<15>(acc[3], Rd[G], w3.v[3]);
     __builtin_amdgcn_sched_barrier(0);
 }
-__device__ __forceinline__ float layer_bwd(float (&gw)[kMaxH], const WtLds<float> &wt, int l, int lane, float d, float hin)
+// hrow != nullptr: the 64 activations h_in[0..63] also sit in LDS (the stage record the DMA delivered): their four 16-lane
+// rows are read back replicated -- four conflict-free broadcast reads -- instead of being replicated through
+// v_permlane swaps (3 swaps + 3 copies of VALU time per layer)
+__device__ __forceinline__ float layer_bwd(float (&gw)[kMaxH], const WtLds<float> &wt, int l, int lane, float d, float hin,
+                                           const float *__restrict__ hrow = nullptr)
 {
     const Vec4<float> *wt4 = reinterpret_cast<const Vec4<float> *>(wt.wt + (size_t)l * kMaxH * kMaxH);
     float Rh[4], Rd[4];
-    rows_replicate(hin, Rh);
+    if (hrow != nullptr) {
+        const int p16 = lane & 15;
+        Rh[0] = hrow[p16]; Rh[1] = hrow[16 + p16]; Rh[2] = hrow[32 + p16]; Rh[3] = hrow[48 + p16];
+        // the DPP reads of Rh[] in the asm FMAs need no wait states after an LDS return (not a VALU write), but keep the
+        // compiler from sinking the loads below the asm block boundary
+        asm volatile("" : "+v"(Rh[0]), "+v"(Rh[1]), "+v"(Rh[2]), "+v"(Rh[3]));
+    } else {
+        rows_replicate(hin, Rh);
+    }
     rows_replicate(d, Rd);
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     __builtin_amdgcn_sched_barrier(0);
@@ -922,8 +935,9 @@ __device__ __forceinline__ R mech_vjp(const OdeP<R> &o, R G, R I, R Glu, R GLP1,
 template <typename R, int NL, bool GODE, bool GT, typename Edge, typename Wt>
 __device__ __forceinline__ R rhs_vjp(Edge &e, R (&gwh)[(NL > 1) ? NL - 1 : 1][kMaxH], const Wt &wt,
                                      const OdeP<R> &o, R t, const R (&x)[6], R tvns, R gde, R gd_in, bool use_gd, int lane,
-                                     const MlpActs<R, NL> &acts, R kb, R &go, R *gt_out)
+                                     const MlpActs<R, NL> &acts, R kb, R &go, R *gt_out, const R *__restrict__ hrows = nullptr)
 {
+    // hrows: LDS copy of the record rows h_2 .. h_NL ([NL-1][64]) or nullptr
     using S = EdgeSlots<NL>;
     // increments of the edge-parameter gradients are collected and applied in ONE batch at the end
     R inc[S::count];
@@ -967,7 +981,7 @@ __device__ __forceinline__ R rhs_vjp(Edge &e, R (&gwh)[(NL > 1) ? NL - 1 : 1][kM
     for (int l = NL - 1; l >= 1; --l) {           // hidden matrix l-1 maps acts.h[l-1] -> acts.h[l]
         const R hin = (l > 1) ? acts.h[l - 1] : h1;
         inc[S::b + l] = d;
-        const R dp = layer_bwd(gwh[l - 1], wt, l - 1, lane, d, hin);   // dW_l += d (x) h_{l-1};  dp = W_l^T d
+        const R dp = layer_bwd(gwh[l - 1], wt, l - 1, lane, d, hin, (l > 1 && hrows) ? hrows + (l - 2) * kWave : nullptr);   // dW_l += d (x) h_{l-1};  dp = W_l^T d
         d = (hin > R(0)) ? dp : R(0);
     }
     inc[S::b + 0] = d;

@@ -193,6 +193,7 @@ __global__ __launch_bounds__(WTREG ? 256 : 64 * kBwdWaves, (sizeof(R) == 4 && !W
                 // the stage state: six wave-uniform (scalar) loads from the compact tail of the record
                 const R *__restrict__ sx = stg + ((size_t)st * 6 + s) * kSlot + kRows * kWave;
                 const R xs[6] = {sx[0], sx[1], sx[2], sx[3], sx[4], sx[5]};
+                const R *__restrict__ hrows = rec + cur * kBuf;      // this stage's rows stay valid until the DMA after next
                 cur ^= 1;
                 // tableau scalars come from LDS with the record (one wait), not from constant memory (an s_load + wait per stage)
                 const R bw_s = rowsT[6 * kWave + s], c_s = rowsT[6 * kWave + 8 + s];
@@ -203,7 +204,7 @@ __global__ __launch_bounds__(WTREG ? 256 : 64 * kBwdWaves, (sizeof(R) == 4 && !W
                 R gde = R(0);
                 if constexpr (use_gd) gde = gd_effect(o, gdv);
                 const R Z = rhs_vjp<R, NL, GODE, false>(E, gwh, wtp, o, ts, xs, rfma(al, dv, v0), gde, gdv, use_gd, lane, ac, kb,
-                                                        go, nullptr);
+                                                        go, nullptr, hrows);
                 ZZ = (grp == s) ? Z : ZZ;
             }
             lam += group_sum8(rowsT[7 * kWave + lane] * ZZ);

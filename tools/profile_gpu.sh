@@ -9,6 +9,8 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
 ARGS="--steps 5 --warmup 2 --train-steps 2 --no-cpu-baseline --no-vi"
+# the kernel sources these counters belong to (bench.py reports PMC traffic only while this hash matches)
+python3 -c "import sys; sys.path.insert(0, '$R'); import bench; print(bench.kernel_source_sha())" > $OUT/kernel_source_sha.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py $ARGS > $OUT/bench_trace.log 2>&1
 echo "trace done"
 for C in FETCH_SIZE WRITE_SIZE "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU" "SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM SQ_INSTS_SMEM GRBM_GUI_ACTIVE"; do

@@ -46,6 +46,8 @@ for k, d in pmc.items():
         d["hbm_bytes_per_launch_corrected"] = (2 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024
         targs = [a.strip() for a in k[k.index("<") + 1:k.rindex(">")].split(",")] if "<" in k else []
         tape_inst = len(targs) >= 5 and targs[4] == "true"          # solve_fwd_kernel<R, NL, METHOD, LB, TAPE, GD>
+        if "generic" in k or "_wg_" in k:
+            continue
         if "solve_fwd" in k and not tape_inst:          # forward-only instantiation (no tape)
             traffic["solve_fwd_hbm_bytes_per_launch"] = d["hbm_bytes_per_launch_corrected"]
             traffic["solve_fwd_fetch_kib_raw"] = d["FETCH_SIZE"]
@@ -59,6 +61,8 @@ for k, d in pmc.items():
                 traffic[f"{key}_hbm_bytes_per_launch"] = d["hbm_bytes_per_launch_corrected"]
 json.dump(out, open(os.path.join(dst, f"{tag}_pmc.json"), "w"), indent=1)
 traffic["source"] = f"profiles/{tag}_pmc.json (2*FETCH_SIZE + WRITE_SIZE) KiB, B=4096 T=241 fp32"
+sha_file = os.path.join(src, "kernel_source_sha.txt")
+traffic["kernel_source_sha"] = open(sha_file).read().strip() if os.path.exists(sha_file) else None
 json.dump(traffic, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
 print(open(os.path.join(dst, f"{tag}_kernel_stats.csv")).read())
 print(json.dumps(traffic, indent=1))
