@@ -45,7 +45,7 @@ template <typename R, int NL> __host__ __device__ constexpr size_t bwd_lds_elems
 {
     return (size_t)(NL > 1 ? NL - 1 : 1) * kMaxH * kMaxH + 8 * kWave +
            (kEdgeLds<R> ? (size_t)(1 + kBwdWaves) * EdgeSlots<NL>::count * kWave : 0) +
-           (size_t)kBwdWaves * 2 * (NL > 1 ? NL - 1 : 1) * kWave;      // rec: [waves][2][NL-1][64] stage-record double buffer
+           (size_t)kBwdWaves * 2 * NL * kWave;      // rec: [waves][2][NL-1 rows + state][64] stage-record double buffer
 }
 
 // The adjoint reads, for every stage of every accepted step, what the forward recorded on the stage
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(WTREG ? 256 : 64 * kBwdWaves, (sizeof(R) == 4 && !W
     const int S = tab.S;
     constexpr int kRows = NL - 1;                     // rows of 64 in a stage record (h_2 .. h_NL) ...
     constexpr int kSlot = kRows * kWave + 8;          // ... followed by the stage state in 8 reals
-    constexpr int kBuf = (kRows > 0 ? kRows : 1) * kWave;   // one half of a wave's record double buffer
+    constexpr int kBuf = kRows * kWave + kWave;       // one half of a wave's record double buffer: the rows + the state (8 of 64 used)
 
     const R *__restrict__ nn_set = a.nn_p + (size_t)set * a.P;
     using ES = EdgeSlots<NL>;
@@ -126,6 +126,12 @@ __global__ __launch_bounds__(WTREG ? 256 : 64 * kBwdWaves, (sizeof(R) == 4 && !W
                 __builtin_amdgcn_global_load_lds(s32 + kWave + lane, (__attribute__((address_space(3))) void *)(d32 + kWave), 4, 0, 0);
             }
         }
+        // the compact stage state (8 reals) rides along, so that it is prefetched one stage ahead like the rows: read
+        // with scalar loads at the point of use it cost an exposed HBM miss per stage (measured: adjoint 8.1 -> 12.7 ms)
+        const float *s32 = reinterpret_cast<const float *>(src + kRows * kWave);
+        float *d32 = reinterpret_cast<float *>(dst + kRows * kWave);
+        if (lane < 8 * (int)(sizeof(R) / 4))
+            __builtin_amdgcn_global_load_lds(s32 + lane, (__attribute__((address_space(3))) void *)d32, 4, 0, 0);
     };
 
     // wave-major distribution: a batch smaller than 8 x the grid keeps every CU busy with fewer active waves each
@@ -190,8 +196,8 @@ __global__ __launch_bounds__(WTREG ? 256 : 64 * kBwdWaves, (sizeof(R) == 4 && !W
                 ac.h[0] = R(0);                                    // h_1 is recomputed inside rhs_vjp
 #pragma unroll
                 for (int l = 1; l < NL; ++l) ac.h[l] = rec[cur * kBuf + (l - 1) * kWave + lane];
-                // the stage state: six wave-uniform (scalar) loads from the compact tail of the record
-                const R *__restrict__ sx = stg + ((size_t)st * 6 + s) * kSlot + kRows * kWave;
+                // the stage state: six broadcast reads of the compact tail of the record (same value on every lane)
+                const R *__restrict__ sx = rec + cur * kBuf + kRows * kWave;
                 const R xs[6] = {sx[0], sx[1], sx[2], sx[3], sx[4], sx[5]};
                 const R *__restrict__ hrows = rec + cur * kBuf;      // this stage's rows stay valid until the DMA after next
                 cur ^= 1;

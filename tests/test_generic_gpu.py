@@ -59,7 +59,7 @@ def test_rhs_fwd_bwd_generic_vs_oracle(hode, golden_dir, g0, H, L):
     x, t, meal, tv, gd = (r[k].astype(np.float64) for k in ("x", "t", "meal", "tvns", "gd"))
     nn, ode = net(H, L), g0["ode"].astype(np.float64)
     w = np.random.default_rng(1).standard_normal(x.shape)
-    for dt, tol_f, tol_g in ((torch.float64, 1e-12, 1e-10), (torch.float32, 5e-6, 3e-5)):
+    for dt, tol_f, tol_g in ((torch.float64, 1e-12, 1e-10), (torch.float32, 5e-5, 1e-4)):      # fp32: states up to 500, gain-0.5 layers
         npdt = np.float64 if dt == torch.float64 else np.float32
         want = O.rhs(x, t, meal, tv, gd, ode, nn, H, L, dtype=np.float64)
         got = hode.rhs_fwd(dev(x, dt), dev(t, dt), dev(meal, dt), dev(tv, dt), dev(gd, dt), dev(ode, dt), dev(nn, dt), H, L)
