@@ -56,7 +56,7 @@ extern "C" {
  *   otherwise            generic kernels (two hidden units per lane, weights streamed from L2, gradients by coalesced
  *                        atomics), same results contract, sized for the batches such shapes are trained with.
  * Activation: ReLU, no dropout.  NNResidual also offers tanh / elu / leaky_relu(0.1) and dropout, but HybridODENN
- * (models/hybrid_ode_nn.py:55-60) never passes either, so no caller of this path can select them: the host class raises
+ * (models/hybrid_ode_nn.py:57-58) never passes either, so no caller of this path can select them: the host class raises
  * NotImplementedError for them instead of silently computing something else. */
 #define HODE_MAX_HIDDEN 128
 #define HODE_MAX_LAYERS 8
