@@ -46,8 +46,8 @@ PEAK_HBM_GBS = 8000.0
 # adjoint, per stage of an accepted step: outer products dW += delta (x) h and the W^T delta products = 2x the MACs of the
 # forward RHS (nothing is recomputed: activations come from the stage tape), plus the mechanistic J^T and edge layers
 FLOP_PER_ADJ_STAGE = 2 * FLOP_PER_RHS
-# stage tape record = h_2..h_L ((L-1) rows x 64 lanes) + the stage state (8) reals per stage; tape entry 32 B + 4 B interval index per step
-STAGE_REC_BYTES = ((L - 1) * 64 + 8) * 4
+# stage tape record = h_1..h_L (L rows x 64 lanes) + the stage state (8) reals per stage; tape entry 32 B + 4 B interval index per step
+STAGE_REC_BYTES = (L * 64 + 8) * 4
 # 4GI generator (K7): per RHS ~60 add/mul/div + 3 pow (exp(p log x), ~40 flop each); DP5(4) stage algebra of 8 states
 FLOP_PER_4GI_RHS = 60 + 3 * 40
 FLOP_PER_4GI_STEP = 6 * FLOP_PER_4GI_RHS + 8 * 2 * (21 + 7) + 40

@@ -826,10 +826,9 @@ __device__ __forceinline__ void edge_table_store(R *__restrict__ tab, const R *_
         R v = R(0);
         if (j < H) {
             if (slot < S::b) v = p[j * 9 + slot];
-            else if (slot == S::b) v = p[9 * H + j];                     // b_1: the VJP recomputes h_1
             else if (slot >= S::w5 && slot < S::b5) v = pout[(slot - S::w5) * H + j];
         }
-        tab[i] = v;            // the other bias slots hold no weight the VJP needs
+        tab[i] = v;            // bias slots hold no weight the VJP needs
     }
 }
 // flush the edge accumulators into the flat gradient vector
@@ -929,31 +928,23 @@ __device__ __forceinline__ R mech_vjp(const OdeP<R> &o, R G, R I, R Glu, R GLP1,
 // same layout and accumulates parameter gradients.  acts = activations of this evaluation (from
 // rhs_eval<KEEP> or from the stage tape).  Needs only the first/last layer weights in registers;
 // the hidden matrices come transposed from LDS (wt).   GODE: also d/d(ode constants) (wave-uniform values).
-//   x[6]  the stage state as six wave-uniform values (scalar loads from the compact stage record / the input batch)
-//   acts  h_2 .. h_NL of this evaluation in acts.h[1 .. NL-1]; h_1 = acts.h[0] is NOT read: it is recomputed here from
-//         (t, x, tvns) with the first-layer weights of the edge table (9 FMAs instead of a 256-byte tape row per stage)
+//   Y     the stage state in the replicated layout (lane l holds x_{l&7}; from the compact stage record / the input batch)
+//   acts  h_1 .. h_NL of this evaluation.  (Recomputing h_1 here from (t, x, tvns) -- 9 FMAs instead of a 256-byte tape row
+//         per stage -- was built and measured: it costs the adjoint kernel its last registers, 80 B of scratch with
+//         reloads inside the stage loop, whose vmcnt waits serialise behind the record DMA: 8.1 -> 12.5 ms.)
 template <typename R, int NL, bool GODE, bool GT, typename Edge, typename Wt>
 __device__ __forceinline__ R rhs_vjp(Edge &e, R (&gwh)[(NL > 1) ? NL - 1 : 1][kMaxH], const Wt &wt,
-                                     const OdeP<R> &o, R t, const R (&x)[6], R tvns, R gde, R gd_in, bool use_gd, int lane,
+                                     const OdeP<R> &o, R t, R Y, R tvns, R gde, R gd_in, bool use_gd, int lane,
                                      const MlpActs<R, NL> &acts, R kb, R &go, R *gt_out, const R *__restrict__ hrows = nullptr)
 {
-    // hrows: LDS copy of the record rows h_2 .. h_NL ([NL-1][64]) or nullptr
+    // hrows: LDS copy of the record rows h_1 .. h_NL ([NL][64]) or nullptr
     using S = EdgeSlots<NL>;
     // increments of the edge-parameter gradients are collected and applied in ONE batch at the end
     R inc[S::count];
-    const R G = x[0], I = x[1], Glu = x[2], GLP1 = x[3], GE = x[4], FFA = x[5];
+    const R G = lane_bcast(Y, 0), I = lane_bcast(Y, 1), Glu = lane_bcast(Y, 2), GLP1 = lane_bcast(Y, 3),
+            GE = lane_bcast(Y, 4), FFA = lane_bcast(Y, 5);
     // h_1 exactly as rhs_eval computes it (same operation order)
-    R h1 = e.W(S::b + 0);
-    h1 = rfma(e.W(S::w1 + 0), t, h1);
-    h1 = rfma(e.W(S::w1 + 1), G, h1);
-    h1 = rfma(e.W(S::w1 + 2), I, h1);
-    h1 = rfma(e.W(S::w1 + 3), Glu, h1);
-    h1 = rfma(e.W(S::w1 + 4), GLP1, h1);
-    h1 = rfma(e.W(S::w1 + 5), GE, h1);
-    h1 = rfma(e.W(S::w1 + 6), FFA, h1);
-    h1 = rfma(e.W(S::w1 + 7), GLP1, h1);
-    h1 = rfma(e.W(S::w1 + 8), tvns, h1);
-    h1 = rmax0(h1);
+    const R h1 = acts.h[0];
     const R lG = lane_bcast(kb, 0), lI = lane_bcast(kb, 1), lGlu = lane_bcast(kb, 2), lGLP = lane_bcast(kb, 3),
             lGE = lane_bcast(kb, 4), lF = lane_bcast(kb, 5);
     const int c8 = lane & 7;
@@ -981,7 +972,7 @@ __device__ __forceinline__ R rhs_vjp(Edge &e, R (&gwh)[(NL > 1) ? NL - 1 : 1][kM
     for (int l = NL - 1; l >= 1; --l) {           // hidden matrix l-1 maps acts.h[l-1] -> acts.h[l]
         const R hin = (l > 1) ? acts.h[l - 1] : h1;
         inc[S::b + l] = d;
-        const R dp = layer_bwd(gwh[l - 1], wt, l - 1, lane, d, hin, (l > 1 && hrows) ? hrows + (l - 2) * kWave : nullptr);   // dW_l += d (x) h_{l-1};  dp = W_l^T d
+        const R dp = layer_bwd(gwh[l - 1], wt, l - 1, lane, d, hin, hrows ? hrows + (l - 1) * kWave : nullptr);   // dW_l += d (x) h_{l-1};  dp = W_l^T d
         d = (hin > R(0)) ? dp : R(0);
     }
     inc[S::b + 0] = d;

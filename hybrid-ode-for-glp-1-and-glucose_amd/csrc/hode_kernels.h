@@ -98,9 +98,9 @@ inline size_t tape_stage_offset(int B, int max_steps, size_t elem)
     size_t o = tape_seg_offset(B, max_steps, elem) + (size_t)B * max_steps * sizeof(int32_t);
     return (o + 255) & ~(size_t)255;
 }
-// reals per stage record: tuned path h_2..h_L (L - 1 rows of 64) + 8 for the stage state; generic path 2 L rows (two hidden
-// units per lane, all layers) + 8
-inline size_t tape_slot_elems(int H, int L) { return (size_t)(tuned_shape(H, L) ? L - 1 : 2 * L) * 64 + 8; }
+// reals per stage record: h_1..h_L (tuned path: L rows of 64; generic path: 2 L rows, two hidden units per lane) + 8 for the
+// stage state
+inline size_t tape_slot_elems(int H, int L) { return (size_t)(tuned_shape(H, L) ? L : 2 * L) * 64 + 8; }
 inline size_t tape_total_bytes(int B, int max_steps, size_t elem, int H, int L)
 {
     return tape_stage_offset(B, max_steps, elem) + (size_t)B * max_steps * 6 * tape_slot_elems(H, L) * elem;

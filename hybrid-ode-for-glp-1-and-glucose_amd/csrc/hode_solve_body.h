@@ -31,9 +31,9 @@ template <typename R, int NL, typename WT> struct RhsRegs {
     const OdeP<R> &o;
     int lane;
     static constexpr bool kKeep = true;
-    // stage record of the tuned path: h_2 .. h_NL (rows of 64) | the 6-vector stage state in 8 reals.  h_1 is not recorded
-    // (the adjoint recomputes it: 9 FMAs), the state is read back with scalar loads -- 800 B per stage for (64,4) in fp32
-    __device__ __forceinline__ int slot_elems() const { return (NL - 1) * kWave + 8; }
+    // stage record of the tuned path: h_1 .. h_NL (rows of 64) | the 6-vector stage state in 8 reals (the replicated
+    // 64-lane copy of the state would be another 256-byte row): 1 056 B per stage for (64,4) in fp32
+    __device__ __forceinline__ int slot_elems() const { return NL * kWave + 8; }
     __device__ __forceinline__ R operator()(R ts, R Ys, R meal, R tvns, R gde, R *__restrict__ rec) const
     {
         if (rec != nullptr) {
@@ -41,8 +41,8 @@ template <typename R, int NL, typename WT> struct RhsRegs {
             const R F = rhs_eval<R, NL, true>(W, o, ts, Ys, meal, tvns, gde, lane, &ac);
             R *dst = rec + lane;
 #pragma unroll
-            for (int l = 1; l < NL; ++l) dst[(l - 1) * kWave] = ac.h[l];
-            if (lane < 8) dst[(NL - 1) * kWave] = Ys;
+            for (int l = 0; l < NL; ++l) dst[l * kWave] = ac.h[l];
+            if (lane < 8) dst[NL * kWave] = Ys;
             return F;
         }
         return rhs_eval<R, NL, false>(W, o, ts, Ys, meal, tvns, gde, lane, nullptr);

@@ -8,8 +8,8 @@
 // CPU restatement: oracle/hode_oracle_impl.h (hode_oracle_solve_bwd).
 //
 // Mapping: one trajectory per wavefront, one hidden unit per lane (see hode_device.h).
-//   * the forward recorded, for every stage of every accepted step, the hidden activations h_2..h_L and the
-//     stage state on the "stage tape" in HBM (4.8 KB per step in fp32; h_1 is recomputed): the adjoint streams them back
+//   * the forward recorded, for every stage of every accepted step, the layer activations and the (compact)
+//     stage state on the "stage tape" in HBM (6.3 KB per step in fp32): the adjoint streams them back
 //     by LDS-DMA (global_load ... lds, one stage ahead, double buffered) instead of recomputing the
 //     forward -- a memory-for-compute trade that 288 GB / 8 TB/s of HBM3E make cheap;
 //   * lane j keeps row j of the three hidden-matrix gradient accumulators in VGPRs (192 registers in
@@ -39,13 +39,13 @@ template <typename R> __device__ __forceinline__ R inp_at_b(const R *__restrict_
 constexpr int kBwdWaves = 8;
 //   edgeW [16+NL][64]       first/last layer weights (fp32 build; shared)
 //   edgeG [waves][16+NL][64] first/last layer gradient accumulators (fp32 build; per wave)
-//   rec   [waves][2][NL-1][64] stage records (h_2..h_NL) arriving by LDS-DMA (global_load ... lds), double buffered
+//   rec   [waves][2][NL+1][64] stage records (h_1..h_NL, state) arriving by LDS-DMA (global_load ... lds), double buffered
 template <typename R> constexpr bool kEdgeLds = (sizeof(R) == 4);
 template <typename R, int NL> __host__ __device__ constexpr size_t bwd_lds_elems()
 {
     return (size_t)(NL > 1 ? NL - 1 : 1) * kMaxH * kMaxH + 8 * kWave +
            (kEdgeLds<R> ? (size_t)(1 + kBwdWaves) * EdgeSlots<NL>::count * kWave : 0) +
-           (size_t)kBwdWaves * 2 * NL * kWave;      // rec: [waves][2][NL-1 rows + state][64] stage-record double buffer
+           (size_t)kBwdWaves * 2 * (NL + 1) * kWave;      // rec: [waves][2][NL rows + state][64] stage-record double buffer
 }
 
 // The adjoint reads, for every stage of every accepted step, what the forward recorded on the stage
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(WTREG ? 256 : 64 * kBwdWaves, (sizeof(R) == 4 && !W
     const int per_set = a.B / a.n_sets;
     const TableauData &tab = kTableau[method];
     const int S = tab.S;
-    constexpr int kRows = NL - 1;                     // rows of 64 in a stage record (h_2 .. h_NL) ...
+    constexpr int kRows = NL;                         // rows of 64 in a stage record (h_1 .. h_NL) ...
     constexpr int kSlot = kRows * kWave + 8;          // ... followed by the stage state in 8 reals
     constexpr int kBuf = kRows * kWave + kWave;       // one half of a wave's record double buffer: the rows + the state (8 of 64 used)
 
@@ -91,7 +91,6 @@ __global__ __launch_bounds__(WTREG ? 256 : 64 * kBwdWaves, (sizeof(R) == 4 && !W
         for (int i = 0; i < ES::count; ++i) { E.w[i] = R(0); E.gacc[i] = R(0); }
 #pragma unroll
         for (int i = 0; i < 9; ++i) E.w[ES::w1 + i] = livej * nn_set[j * 9 + i];
-        E.w[ES::b + 0] = livej * nn_set[9 * a.H + j];       // b_1: the VJP recomputes h_1
 #pragma unroll
         for (int q = 0; q < 6; ++q) E.w[ES::w5 + q] = livej * pout[q * a.H + j];
     }
@@ -113,7 +112,7 @@ __global__ __launch_bounds__(WTREG ? 256 : 64 * kBwdWaves, (sizeof(R) == 4 && !W
     R go = R(0);                                  // lane p < 17: d/d(ode constant p), summed over this wave's trajectories
     R *rec = rowsT + 8 * kWave + (kEdgeLds<R> ? (size_t)(1 + kBwdWaves) * EdgeSlots<NL>::count * kWave : 0) +
              (size_t)wave * 2 * kBuf;
-    // the DMA'd part of a record = NL - 1 rows of 64 reals; each row is one (fp32) or two (fp64) 4-byte-per-lane DMA instructions
+    // the DMA'd part of a record = NL rows of 64 reals; each row is one (fp32) or two (fp64) 4-byte-per-lane DMA instructions
     auto rec_dma = [&](const R *__restrict__ src, R *dst) {
 #pragma unroll
         for (int l = 0; l < kRows; ++l) {
@@ -193,12 +192,11 @@ __global__ __launch_bounds__(WTREG ? 256 : 64 * kBwdWaves, (sizeof(R) == 4 && !W
                 const int nst = (s > 0) ? st : st - 1, ns_ = (s > 0) ? s - 1 : S - 1;
                 if (nst >= 0) rec_dma(stg + ((size_t)nst * 6 + ns_) * kSlot, rec + (cur ^ 1) * kBuf);
                 MlpActs<R, NL> ac;
-                ac.h[0] = R(0);                                    // h_1 is recomputed inside rhs_vjp
 #pragma unroll
-                for (int l = 1; l < NL; ++l) ac.h[l] = rec[cur * kBuf + (l - 1) * kWave + lane];
-                // the stage state: six broadcast reads of the compact tail of the record (same value on every lane)
-                const R *__restrict__ sx = rec + cur * kBuf + kRows * kWave;
-                const R xs[6] = {sx[0], sx[1], sx[2], sx[3], sx[4], sx[5]};
+                for (int l = 0; l < NL; ++l) ac.h[l] = rec[cur * kBuf + l * kWave + lane];
+                // the stage state, back in the replicated layout: lane l reads slot l & 7 of the compact tail of the record
+                // (six uniform values kept as six VGPRs instead cost the kernel its last registers: 108 B of scratch, 8.1 -> 12.5 ms)
+                const R Ys = rec[cur * kBuf + kRows * kWave + c8];
                 const R *__restrict__ hrows = rec + cur * kBuf;      // this stage's rows stay valid until the DMA after next
                 cur ^= 1;
                 // tableau scalars come from LDS with the record (one wait), not from constant memory (an s_load + wait per stage)
@@ -209,7 +207,7 @@ __global__ __launch_bounds__(WTREG ? 256 : 64 * kBwdWaves, (sizeof(R) == 4 && !W
                 const R gdv = rfma(al, dd, d0);
                 R gde = R(0);
                 if constexpr (use_gd) gde = gd_effect(o, gdv);
-                const R Z = rhs_vjp<R, NL, GODE, false>(E, gwh, wtp, o, ts, xs, rfma(al, dv, v0), gde, gdv, use_gd, lane, ac, kb,
+                const R Z = rhs_vjp<R, NL, GODE, false>(E, gwh, wtp, o, ts, Ys, rfma(al, dv, v0), gde, gdv, use_gd, lane, ac, kb,
                                                         go, nullptr, hrows);
                 ZZ = (grp == s) ? Z : ZZ;
             }
@@ -354,7 +352,6 @@ __global__ __launch_bounds__(256, 1) void rhs_bwd_kernel(const RhsArgs<R> a)
     for (int i = 0; i < ES::count; ++i) { E.w[i] = R(0); E.gacc[i] = R(0); }
 #pragma unroll
     for (int i = 0; i < 9; ++i) E.w[ES::w1 + i] = W.w1[i];
-    E.w[ES::b + 0] = W.b[0];
 #pragma unroll
     for (int q = 0; q < 6; ++q) E.w[ES::w5 + q] = W.w5[q];
     R gwh[(NL > 1) ? NL - 1 : 1][kMaxH];
@@ -374,9 +371,7 @@ __global__ __launch_bounds__(256, 1) void rhs_bwd_kernel(const RhsArgs<R> a)
         MlpActs<R, NL> ac;
         (void)rhs_eval<R, NL, true>(W, o, t, Y, meal, tvns, gde, lane, &ac);
         R gt;
-        const R *__restrict__ xp = a.x + (size_t)s * 6;     // wave-uniform: scalar loads
-        const R xs[6] = {xp[0], xp[1], xp[2], xp[3], xp[4], xp[5]};
-        const R Z = rhs_vjp<R, NL, GODE, true>(E, gwh, WtLds<R>{wt}, o, t, xs, tvns, gde, gdv, a.gd != nullptr, lane, ac, kb, go, &gt);
+        const R Z = rhs_vjp<R, NL, GODE, true>(E, gwh, WtLds<R>{wt}, o, t, Y, tvns, gde, gdv, a.gd != nullptr, lane, ac, kb, go, &gt);
         if (lane < 6) a.gx[(size_t)s * 6 + lane] = Z;
         if (a.gt && lane == 0) a.gt[s] = gt;
     }

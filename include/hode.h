@@ -70,10 +70,9 @@ int hode_nn_param_count(int H, int L);
 
 /* bytes of the tape the solve writes for the adjoint: per accepted step {t, h, y[6]}, the grid
  * interval (bit 30 set when the step ended exactly on the grid point closing that interval), and the "stage tape" -- the
- * MLP activations and stage state of every Runge-Kutta stage (tuned path: h_2..h_L and the state, 6 x ((L-1) x 64 + 8) reals
- * per step -- h_1 is recomputed by the adjoint; generic path: 6 x (2L x 64 + 8)), so that the adjoint never re-runs the hidden
- * layers.  This is a memory-for-compute trade sized for 288 GB of HBM: 4.8 KB per step in fp32 for (64,4), i.e.
- * 1.4 MB per trajectory at max_steps = 300.  hode_tape_bytes(.., L) == hode_tape_bytes_hl(.., 64, L). */
+ * MLP activations and stage state of every Runge-Kutta stage (tuned path 6 x (L x 64 + 8) reals per step, generic path
+ * 6 x (2L x 64 + 8)), so that the adjoint never re-runs the forward.  This is a memory-for-compute trade sized for
+ * 288 GB of HBM: 6.3 KB per step in fp32 for (64,4), i.e. 1.9 MB per trajectory at max_steps = 300.  hode_tape_bytes(.., L) == hode_tape_bytes_hl(.., 64, L). */
 size_t hode_tape_bytes_hl(int B, int max_steps, int elem_size /* 4 or 8 */, int H, int L);
 size_t hode_tape_bytes(int B, int max_steps, int elem_size /* 4 or 8 */, int L);
 
