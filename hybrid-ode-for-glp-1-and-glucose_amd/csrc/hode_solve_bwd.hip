@@ -37,15 +37,23 @@ template <typename R> __device__ __forceinline__ R inp_at_b(const R *__restrict_
 //   wt    [(NL-1)][64*64]   transposed hidden matrices, rotating-operand order (hode_device.h: wt_rot_store)
 //   rowsT [8][64]           transposed tableau rows A[lane>>3][s]; row 7 = 1 for the solution stages
 constexpr int kBwdWaves = 8;
+// stage records in flight AHEAD of the one being processed (LDS-DMA ring of kBwdAhead + 1 slots per wave): one record ahead
+// is ~2 900 cycles of lead, about the loaded-HBM latency; two hide it (measured)
+#ifndef HODE_BWD_AHEAD
+#define HODE_BWD_AHEAD 2
+#endif
+// fp64 (parity builds): the 96 KB transposed-matrix image leaves room for one record ahead only
+template <typename R> constexpr int kBwdAhead = (sizeof(R) == 4) ? HODE_BWD_AHEAD : 1;
+template <typename R> constexpr int kBwdRing = kBwdAhead<R> + 1;
 //   edgeW [16+NL][64]       first/last layer weights (fp32 build; shared)
 //   edgeG [waves][16+NL][64] first/last layer gradient accumulators (fp32 build; per wave)
-//   rec   [waves][2][NL+1][64] stage records (h_1..h_NL, state) arriving by LDS-DMA (global_load ... lds), double buffered
+//   rec   [waves][ring][NL+1][64] stage records (h_1..h_NL, state) arriving by LDS-DMA (global_load ... lds)
 template <typename R> constexpr bool kEdgeLds = (sizeof(R) == 4);
 template <typename R, int NL> __host__ __device__ constexpr size_t bwd_lds_elems()
 {
     return (size_t)(NL > 1 ? NL - 1 : 1) * kMaxH * kMaxH + 8 * kWave +
            (kEdgeLds<R> ? (size_t)(1 + kBwdWaves) * EdgeSlots<NL>::count * kWave : 0) +
-           (size_t)kBwdWaves * 2 * (NL + 1) * kWave;      // rec: [waves][2][NL rows + state][64] stage-record double buffer
+           (size_t)kBwdWaves * kBwdRing<R> * (NL + 1) * kWave;      // rec: [waves][ring][NL rows + state][64] stage-record ring
 }
 
 // The adjoint reads, for every stage of every accepted step, what the forward recorded on the stage
@@ -71,7 +79,8 @@ __global__ __launch_bounds__(WTREG ? 256 : 64 * kBwdWaves, (sizeof(R) == 4 && !W
     const int S = tab.S;
     constexpr int kRows = NL;                         // rows of 64 in a stage record (h_1 .. h_NL) ...
     constexpr int kSlot = kRows * kWave + 8;          // ... followed by the stage state in 8 reals
-    constexpr int kBuf = kRows * kWave + kWave;       // one half of a wave's record double buffer: the rows + the state (8 of 64 used)
+    constexpr int kBuf = kRows * kWave + kWave;       // one slot of a wave's record ring: the rows + the state (8 of 64 used)
+    constexpr int kRing = kBwdRing<R>;
 
     const R *__restrict__ nn_set = a.nn_p + (size_t)set * a.P;
     using ES = EdgeSlots<NL>;
@@ -111,7 +120,7 @@ __global__ __launch_bounds__(WTREG ? 256 : 64 * kBwdWaves, (sizeof(R) == 4 && !W
     constexpr bool use_gd = GD;                   // Hill-term code (pow, log) only in the GD instantiation
     R go = R(0);                                  // lane p < 17: d/d(ode constant p), summed over this wave's trajectories
     R *rec = rowsT + 8 * kWave + (kEdgeLds<R> ? (size_t)(1 + kBwdWaves) * EdgeSlots<NL>::count * kWave : 0) +
-             (size_t)wave * 2 * kBuf;
+             (size_t)wave * kRing * kBuf;
     // the DMA'd part of a record = NL rows of 64 reals; each row is one (fp32) or two (fp64) 4-byte-per-lane DMA instructions
     auto rec_dma = [&](const R *__restrict__ src, R *dst) {
 #pragma unroll
@@ -148,8 +157,19 @@ __global__ __launch_bounds__(WTREG ? 256 : 64 * kBwdWaves, (sizeof(R) == 4 && !W
         // Stage records stream HBM -> LDS by DMA (no VGPR destination): while stage s is processed from one
         // half of the wave's double buffer, the record of the next stage (also across step boundaries) lands
         // in the other half.
-        int cur = 0;
-        if (n > 0) rec_dma(stg + ((size_t)(n - 1) * 6 + (S - 1)) * kSlot, rec);
+        // records are consumed in the order (n-1, S-1), (n-1, S-2), ..., (0, 0); (pst, ps) walks kBwdAhead records ahead
+        constexpr int kAhead = kBwdAhead<R>;
+        constexpr int kDmaOps = kRows * (int)(sizeof(R) / 4) + 1;                 // DMA instructions per record
+        constexpr int kWaitYounger = 0x0f70 | ((kDmaOps * (kAhead - 1)) & 15) | (((kDmaOps * (kAhead - 1)) >> 4) << 14);
+        static_assert(kDmaOps * (kAhead - 1) < 64, "vmcnt field");
+        int cur = 0, pst = n - 1, ps = S - 1, ahead = 0;                         // ahead = records issued and not yet consumed
+        auto issue_next = [&]() {
+            if (pst < 0) return;
+            rec_dma(stg + ((size_t)pst * 6 + ps) * kSlot, rec + ((cur + ahead) % kRing) * kBuf);
+            ++ahead;
+            if (--ps < 0) { ps = S - 1; --pst; }
+        };
+        for (int j = 0; j < kAhead; ++j) issue_next();
 #pragma unroll 1
         for (int st = n - 1; st >= 0; --st) {
             const int kraw = tseg[st];
@@ -186,19 +206,26 @@ __global__ __launch_bounds__(WTREG ? 256 : 64 * kBwdWaves, (sizeof(R) == 4 && !W
             R ZZ = R(0);
 #pragma unroll 1
             for (int s = S - 1; s >= 0; --s) {
-                // record (st, s) was DMA'd into rec[cur] one stage ago: drain the DMA, then start the next one
-                __builtin_amdgcn_s_waitcnt(0x0f70);            // vmcnt(0): the only outstanding VMEM ops are our DMAs
+                // record (st, s) was DMA'd into ring slot `cur` kBwdAhead stages ago.  The only outstanding VMEM ops are our
+                // DMAs and they complete in issue order: wait until at most the YOUNGER records are still in flight
+                if (ahead == kAhead && kAhead > 1) __builtin_amdgcn_s_waitcnt(kWaitYounger);
+                else __builtin_amdgcn_s_waitcnt(0x0f70);       // vmcnt(0): tail of the trajectory
                 __builtin_amdgcn_wave_barrier();
-                const int nst = (s > 0) ? st : st - 1, ns_ = (s > 0) ? s - 1 : S - 1;
-                if (nst >= 0) rec_dma(stg + ((size_t)nst * 6 + ns_) * kSlot, rec + (cur ^ 1) * kBuf);
+                --ahead;                                       // slot `cur` is being consumed; the slot behind the ring frees up
+                {
+                    const int keep = cur;
+                    cur = (cur + 1) % kRing;                   // issue_next() addresses slots relative to the NEXT record
+                    issue_next();
+                    cur = keep;
+                }
                 MlpActs<R, NL> ac;
 #pragma unroll
                 for (int l = 0; l < NL; ++l) ac.h[l] = rec[cur * kBuf + l * kWave + lane];
                 // the stage state, back in the replicated layout: lane l reads slot l & 7 of the compact tail of the record
                 // (six uniform values kept as six VGPRs instead cost the kernel its last registers: 108 B of scratch, 8.1 -> 12.5 ms)
                 const R Ys = rec[cur * kBuf + kRows * kWave + c8];
-                const R *__restrict__ hrows = rec + cur * kBuf;      // this stage's rows stay valid until the DMA after next
-                cur ^= 1;
+                const R *__restrict__ hrows = rec + cur * kBuf;      // this stage's rows stay valid until the ring comes round
+                cur = (cur + 1) % kRing;
                 // tableau scalars come from LDS with the record (one wait), not from constant memory (an s_load + wait per stage)
                 const R bw_s = rowsT[6 * kWave + s], c_s = rowsT[6 * kWave + 8 + s];
                 const R kb = h * rfma(bw_s, lam, group_sum8(rowsT[s * kWave + lane] * ZZ));
