@@ -64,14 +64,22 @@ __device__ __forceinline__ R rhs_stream(const StreamNet<R> &n, const OdeP<R> &o,
     for (int l = 0; l + 1 < L; ++l) {
         const R *__restrict__ rowA = n.Wh(l) + (size_t)jA * H, *__restrict__ rowB = n.Wh(l) + (size_t)jB * H;
         R aA = n.bh(l)[jA], aB = n.bh(l)[jB];
-        const int H0 = H < 64 ? H : 64;
-        for (int k = 0; k < H0; ++k) {                          // units 0..63 live in hA
-            const R hk = bcast_dyn(hA, k);
-            aA = rfma(rowA[k], hk, aA);
-            aB = rfma(rowB[k], hk, aB);
+        // chunks of 8 columns: 16 independent loads in flight, then the 16 FMAs (one load, one dependent FMA at a time left
+        // a lone wave waiting out an L2 round trip per column: 22 ms per 32 x 61 forward, now 5 ms)
+        int k = 0;
+        for (; k + 8 <= H; k += 8) {
+            R wA[8], wB[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { wA[u] = rowA[k + u]; wB[u] = rowB[k + u]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const R hk = unit_bcast(hA, hB, k + u);        // k + u < 64 for the whole chunk or >= 64 for the whole chunk
+                aA = rfma(wA[u], hk, aA);
+                aB = rfma(wB[u], hk, aB);
+            }
         }
-        for (int k = 64; k < H; ++k) {                          // units 64..127 in hB
-            const R hk = bcast_dyn(hB, k - 64);
+        for (; k < H; ++k) {
+            const R hk = unit_bcast(hA, hB, k);
             aA = rfma(rowA[k], hk, aA);
             aB = rfma(rowB[k], hk, aB);
         }
@@ -137,11 +145,31 @@ __device__ __forceinline__ R rhs_vjp_stream(const StreamNet<R> &n, R *__restrict
             if (vB) atomic_add(gW + (size_t)H * H + jB, dB);
         }
         R pA = R(0), pB = R(0);
-        for (int j = 0; j < H; ++j) {
+        int j = 0;
+        for (; j + 4 <= H; j += 4) {                           // four rows at a time: 8 independent loads in flight
+            R wA[4], wB[4], dj[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const R *__restrict__ row = W + (size_t)(j + u) * H;
+                wA[u] = row[jA];                                // column jA / jB of row j: 256 contiguous bytes per wave
+                wB[u] = row[jB];
+                dj[u] = unit_bcast(dA, dB, j + u);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                pA = rfma(wA[u], dj[u], pA);                    // a dead unit (ReLU, dj == 0) adds nothing
+                pB = rfma(wB[u], dj[u], pB);
+                if (g && dj[u] != R(0)) {                       // wave-uniform test: no atomics for dead units
+                    if (vA) atomic_add(gW + (size_t)(j + u) * H + jA, dj[u] * inA);
+                    if (vB) atomic_add(gW + (size_t)(j + u) * H + jB, dj[u] * inB);
+                }
+            }
+        }
+        for (; j < H; ++j) {
             const R dj = unit_bcast(dA, dB, j);
-            if (dj == R(0)) continue;                          // wave-uniform: dead unit (ReLU) -- nothing to add, nothing to propagate
+            if (dj == R(0)) continue;
             const R *__restrict__ row = W + (size_t)j * H;
-            pA = rfma(row[jA], dj, pA);                         // column jA / jB of row j: 256 contiguous bytes per wave
+            pA = rfma(row[jA], dj, pA);
             pB = rfma(row[jB], dj, pB);
             if (g) {
                 if (vA) atomic_add(gW + (size_t)j * H + jA, dj * inA);
