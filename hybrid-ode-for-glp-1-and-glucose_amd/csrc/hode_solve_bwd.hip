@@ -37,10 +37,11 @@ template <typename R> __device__ __forceinline__ R inp_at_b(const R *__restrict_
 //   wt    [(NL-1)][64*64]   transposed hidden matrices, rotating-operand order (hode_device.h: wt_rot_store)
 //   rowsT [8][64]           transposed tableau rows A[lane>>3][s]; row 7 = 1 for the solution stages
 constexpr int kBwdWaves = 8;
-// stage records in flight AHEAD of the one being processed (LDS-DMA ring of kBwdAhead + 1 slots per wave): one record ahead
-// is ~2 900 cycles of lead, about the loaded-HBM latency; two hide it (measured)
+// stage records in flight AHEAD of the one being processed (LDS-DMA ring of kBwdAhead<R> + 1 slots per wave).  One record
+// ahead is ~2 900 cycles of lead; two (-DHODE_BWD_AHEAD=2, counted vmcnt wait) were measured at the same 8.1 ms: the
+// record DMA is not what the stage loop waits for
 #ifndef HODE_BWD_AHEAD
-#define HODE_BWD_AHEAD 2
+#define HODE_BWD_AHEAD 1
 #endif
 // fp64 (parity builds): the 96 KB transposed-matrix image leaves room for one record ahead only
 template <typename R> constexpr int kBwdAhead = (sizeof(R) == 4) ? HODE_BWD_AHEAD : 1;
