@@ -81,9 +81,11 @@ def test_solve_and_adjoint_generic_fp64_vs_oracle(hode, golden_dir, g0, H, L):
     c = np.random.default_rng(2).standard_normal((x0.shape[0], len(t), 6))
     dt = torch.float64
     for method in (O.METHOD_DP54, O.METHOD_RK4):
-        ref = O.solve(x0, t, meal, tv, None, ode, nn, H, L, method=method, rtol=1e-8, atol=1e-10, dtype=np.float64, want_tape=True)
+        ms = 1500 if method == O.METHOD_DP54 else None         # same step budget on both sides (the lively test networks take 20-30 steps per interval)
+        ref = O.solve(x0, t, meal, tv, None, ode, nn, H, L, method=method, rtol=1e-8, atol=1e-10, dtype=np.float64, want_tape=True,
+                      max_steps=ms)
         s = hode.solve_fwd(dev(x0, dt), dev(t, dt), dev(meal, dt), dev(tv, dt), None, dev(ode, dt), dev(nn, dt), H, L, method=method,
-                           rtol=1e-8, atol=1e-10, want_tape=True)
+                           rtol=1e-8, atol=1e-10, want_tape=True, max_steps=ms)
         assert int(s.status.max()) == 0 and np.array_equal(s.nsteps.cpu().numpy(), ref.nsteps), (H, L, method)
         # same algorithm, same dtype, different summation order inside a layer: the adaptive controller (hundreds of steps at
         # 1e-8 for these lively networks) turns last-bit differences into tolerance-sized ones; RK4 has no controller
@@ -95,7 +97,7 @@ def test_solve_and_adjoint_generic_fp64_vs_oracle(hode, golden_dir, g0, H, L):
         assert relnorm(gode.cpu().numpy(), rode) < 10 * tg
         # without a tape: same trajectories
         s2 = hode.solve_fwd(dev(x0, dt), dev(t, dt), dev(meal, dt), dev(tv, dt), None, dev(ode, dt), dev(nn, dt), H, L, method=method,
-                            rtol=1e-8, atol=1e-10)
+                            rtol=1e-8, atol=1e-10, max_steps=ms)
         assert torch.equal(s2.y, s.y)
 
 
@@ -109,7 +111,8 @@ def test_reference_ablation_shape_fp32_forward_adjoint_and_sets(hode, golden_dir
     t = g["t"].astype(np.float64)
     nn, ode = net(H, L), g0["ode"].astype(np.float64)
     f32 = torch.float32
-    s = hode.solve_fwd(dev(x0, f32), dev(t, f32), dev(meal, f32), dev(tv, f32), None, dev(ode, f32), dev(nn, f32), H, L, want_tape=True)
+    s = hode.solve_fwd(dev(x0, f32), dev(t, f32), dev(meal, f32), dev(tv, f32), None, dev(ode, f32), dev(nn, f32), H, L, want_tape=True,
+                       max_steps=1500)
     ref = O.solve(x0, t, meal, tv, None, ode, nn, H, L, rtol=1e-10, atol=1e-12, dtype=np.float64, want_tape=True)
     assert int(s.status.max()) == 0 and rel(s.y.cpu().numpy(), ref.y) < 1e-4
     bare = O.solve(x0[:4], t, meal[:4], tv[:4], None, ode, np.zeros_like(nn), H, L, rtol=1e-8, atol=1e-10, dtype=np.float64)
@@ -123,11 +126,12 @@ def test_reference_ablation_shape_fp32_forward_adjoint_and_sets(hode, golden_dir
     tb = np.tile(t, (32, 1)) * (1 + 0.01 * np.arange(32)[:, None])
     dt = torch.float64
     s2 = hode.solve_fwd(dev(x0, dt), dev(tb, dt), dev(meal, dt), dev(tv, dt), None, dev(np.concatenate([ode, ode]), dt), dev(nn2, dt), H, L,
-                        n_sets=2, rtol=1e-8, atol=1e-10, want_tape=True)
+                        n_sets=2, rtol=1e-8, atol=1e-10, want_tape=True, max_steps=1500)
     gx2, gnn2, _ = hode.solve_bwd(s2, dev(c, dt))
     P = nn.size
     for k, (p_k, sl) in enumerate(((nn, slice(0, 16)), (0.5 * nn, slice(16, 32)))):
-        r_k = O.solve(x0[sl], tb[sl], meal[sl], tv[sl], None, ode, p_k, H, L, rtol=1e-8, atol=1e-10, dtype=np.float64, want_tape=True)
+        r_k = O.solve(x0[sl], tb[sl], meal[sl], tv[sl], None, ode, p_k, H, L, rtol=1e-8, atol=1e-10, dtype=np.float64, want_tape=True,
+                      max_steps=1500)
         assert rel(s2.y[sl].cpu().numpy(), r_k.y) < 2e-7
         rx_k, rnn_k, _ = O.solve_bwd(r_k, c[sl])
         assert relnorm(gnn2[k * P:(k + 1) * P].cpu().numpy(), rnn_k) < 5e-5 and relnorm(gx2[sl].cpu().numpy(), rx_k) < 5e-5
