@@ -59,7 +59,7 @@ int rhs_fwd(void *stream, int B, const R *x, const R *t, const R *meal, const R 
 template <typename R>
 int solve_bwd(void *stream, int B, int T, const R *t, int t_batched, const R *meal, int meal_mode, const R *tvns,
               int tvns_mode, const R *gd, int gd_mode, const R *ode_p, const R *nn_p, int n_sets, int H, int L,
-              int method, int max_steps, const int32_t *nsteps, const int32_t *status, const void *tape, const R *gy,
+              int method, int max_steps, const int32_t *nsteps, const int32_t *status, void *tape, const R *gy,
               R *gx0, R *gnn, R *gode)
 {
     if (B == 0 && T >= 1) return HODE_OK;
@@ -79,6 +79,7 @@ int solve_bwd(void *stream, int B, int T, const R *t, int t_batched, const R *me
     a.tape_seg = (const int32_t *)((const char *)tape + tape_seg_offset(B, max_steps, sizeof(R)));
     a.tape_stage = (const R *)((const char *)tape + tape_stage_offset(B, max_steps, sizeof(R)));
     a.gy = gy; a.gx0 = gx0; a.gnn = gnn; a.gode = gode;
+    a.tape_delta = has_delta_tape(sizeof(R), H, L) ? (R *)((char *)tape + tape_delta_offset(B, max_steps, sizeof(R), H, L)) : nullptr;
     if (!tuned_shape(H, L)) return launch_solve_bwd_generic<R>((hipStream_t)stream, a, L, method);
     return launch_solve_bwd<R>((hipStream_t)stream, a, L, method);
 }
@@ -159,7 +160,7 @@ int hode_rhs_bwd_f64(void *stream, int B, const double *x, const double *t, cons
 int hode_solve_bwd_f32(void *stream, int B, int T, const float *t, int t_batched, const float *meal, int meal_mode,
                        const float *tvns, int tvns_mode, const float *gd, int gd_mode, const float *ode_p,
                        const float *nn_p, int n_sets, int H, int L, int method, int max_steps, const int32_t *nsteps,
-                       const int32_t *status, const void *tape, const float *gy, float *gx0, float *gnn, float *gode)
+                       const int32_t *status, void *tape, const float *gy, float *gx0, float *gnn, float *gode)
 {
     return solve_bwd<float>(stream, B, T, t, t_batched, meal, meal_mode, tvns, tvns_mode, gd, gd_mode, ode_p, nn_p,
                             n_sets, H, L, method, max_steps, nsteps, status, tape, gy, gx0, gnn, gode);
@@ -167,7 +168,7 @@ int hode_solve_bwd_f32(void *stream, int B, int T, const float *t, int t_batched
 int hode_solve_bwd_f64(void *stream, int B, int T, const double *t, int t_batched, const double *meal, int meal_mode,
                        const double *tvns, int tvns_mode, const double *gd, int gd_mode, const double *ode_p,
                        const double *nn_p, int n_sets, int H, int L, int method, int max_steps, const int32_t *nsteps,
-                       const int32_t *status, const void *tape, const double *gy, double *gx0, double *gnn, double *gode)
+                       const int32_t *status, void *tape, const double *gy, double *gx0, double *gnn, double *gode)
 {
     return solve_bwd<double>(stream, B, T, t, t_batched, meal, meal_mode, tvns, tvns_mode, gd, gd_mode, ode_p, nn_p,
                              n_sets, H, L, method, max_steps, nsteps, status, tape, gy, gx0, gnn, gode);

@@ -27,6 +27,7 @@ template <typename R> struct AdjArgs {
     const R *tape_stage;
     const R *gy;
     R *gx0, *gnn, *gode;
+    R *tape_delta;      // fp32 tuned shapes: [B][max_steps][6][delta_slot_elems] scratch of the split adjoint (part of the tape)
 };
 
 template <typename R> struct RhsArgs {
@@ -101,9 +102,22 @@ inline size_t tape_stage_offset(int B, int max_steps, size_t elem)
 // reals per stage record: h_1..h_L (tuned path: L rows of 64; generic path: 2 L rows, two hidden units per lane) + 8 for the
 // stage state
 inline size_t tape_slot_elems(int H, int L) { return (size_t)(tuned_shape(H, L) ? L : 2 * L) * 64 + 8; }
+// The split adjoint of the tuned fp32 path (hode_solve_bwd_split.hip) hands the layer cotangents of every stage from its
+// propagation kernel to its accumulation kernel through HBM: delta_1..delta_L (L rows of 64) + {kb[6], t, tVNS} in 8 reals per
+// stage, in a region of the tape behind the stage tape (the tape is the adjoint's workspace: nothing is allocated inside the
+// library).  Other dtypes / shapes have no such region.
+inline size_t delta_slot_elems(int L) { return (size_t)L * 64 + 8; }
+inline bool has_delta_tape(size_t elem, int H, int L) { return elem == 4 && tuned_shape(H, L); }
+inline size_t tape_delta_offset(int B, int max_steps, size_t elem, int H, int L)
+{
+    size_t o = tape_stage_offset(B, max_steps, elem) + (size_t)B * max_steps * 6 * tape_slot_elems(H, L) * elem;
+    return (o + 255) & ~(size_t)255;
+}
 inline size_t tape_total_bytes(int B, int max_steps, size_t elem, int H, int L)
 {
-    return tape_stage_offset(B, max_steps, elem) + (size_t)B * max_steps * 6 * tape_slot_elems(H, L) * elem;
+    const size_t o = tape_delta_offset(B, max_steps, elem, H, L);
+    return has_delta_tape(elem, H, L) ? o + (size_t)B * max_steps * 6 * delta_slot_elems(L) * elem : o;
 }
+int launch_solve_bwd_split(hipStream_t s, const AdjArgs<float> &a, int L, int method);   // hode_solve_bwd_split.hip (fp32, tuned shapes)
 
 }  // namespace hode

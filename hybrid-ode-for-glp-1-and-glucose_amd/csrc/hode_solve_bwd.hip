@@ -344,8 +344,18 @@ template <typename R, int NL> static int launch_bwd_nl(hipStream_t s, const AdjA
     return a.gode ? launch_bwd_k<R, NL, true, false>(s, a, method) : launch_bwd_k<R, NL, false, false>(s, a, method);
 }
 
+// fp32, L >= 2: the split adjoint (hode_solve_bwd_split.hip) unless HODE_BWD=fused
+static bool bwd_fused()
+{
+    static const bool v = [] { const char *e = getenv("HODE_BWD"); return e && e[0] == 'f'; }();
+    return v;
+}
+
 template <typename R> int launch_solve_bwd(hipStream_t s, const AdjArgs<R> &a, int L, int method)
 {
+    if constexpr (sizeof(R) == 4) {
+        if (L >= 2 && a.tape_delta && !bwd_fused() && !bwd_wt_in_regs()) return launch_solve_bwd_split(s, a, L, method);
+    }
     switch (L) {
     case 1: return launch_bwd_nl<R, 1>(s, a, method);
     case 2: return launch_bwd_nl<R, 2>(s, a, method);

@@ -119,18 +119,21 @@ int hode_solve_fwd_f64(void *stream, int B, int T, const double *x0, const doubl
 /* ---- K4: reverse-time discrete adjoint of the solve above (no reference counterpart: the
  *      reference detaches the solve; north_star requires it).
  *      gy[B,T,6] = dLoss/dy  ->  gx0[B,6] (written), gnn[n_sets,P] and gode[n_sets,17]
- *      (ACCUMULATED with atomics: zero them first; either may be NULL).                        */
+ *      (ACCUMULATED with atomics: zero them first; either may be NULL).  tape: the buffer the forward filled; its tail
+ *      (fp32, H <= 64, L <= 4) is the adjoint's scratch -- the layer cotangents travel through it from the propagation
+ *      kernel to the accumulation kernel -- so the tape is not const here; what the forward recorded stays intact
+ *      (the same tape may be walked again).                                                      */
 int hode_solve_bwd_f32(void *stream, int B, int T, const float *t, int t_batched,
                        const float *meal, int meal_mode, const float *tvns, int tvns_mode,
                        const float *gd, int gd_mode, const float *ode_p, const float *nn_p,
                        int n_sets, int H, int L, int method, int max_steps, const int32_t *nsteps,
-                       const int32_t *status, const void *tape, const float *gy, float *gx0,
+                       const int32_t *status, void *tape, const float *gy, float *gx0,
                        float *gnn, float *gode);
 int hode_solve_bwd_f64(void *stream, int B, int T, const double *t, int t_batched,
                        const double *meal, int meal_mode, const double *tvns, int tvns_mode,
                        const double *gd, int gd_mode, const double *ode_p, const double *nn_p,
                        int n_sets, int H, int L, int method, int max_steps, const int32_t *nsteps,
-                       const int32_t *status, const void *tape, const double *gy, double *gx0,
+                       const int32_t *status, void *tape, const double *gy, double *gx0,
                        double *gnn, double *gode);
 
 /* ---- K6: fused global-norm clip + Adam.  Replaces clip_grad_norm_(...,5.0) + torch.optim.Adam

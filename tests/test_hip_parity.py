@@ -616,3 +616,47 @@ np.savez({out!r}, y=a.y.cpu().numpy(), yt=b.y.cpu().numpy(), nfev=a.nfev.cpu().n
     ref = O.solve(np.concatenate([g["x0"]] * 5)[:19], g["t"], np.concatenate([g["meal"]] * 5)[:19], np.concatenate([g["tvns"]] * 5)[:19],
                   None, g0["ode"], g0["nn"], 64, 4, dtype=np.float32)
     assert rel(ys["wg"]["y"][:19], ref.y) < 2e-5
+
+
+def test_split_adjoint_matches_the_fused_adjoint(hode, golden_dir, g0, tmp_path):
+    """fp32 production adjoint = two kernels (propagation with W^T in registers -> delta tape -> accumulation;
+    csrc/hode_solve_bwd_split.hip).  HODE_BWD=fused runs the one-kernel adjoint of hode_solve_bwd.hip on the same tape:
+    same gradients up to summation order (both against the fp64 oracle as well), including ODE-constant gradients, two
+    parameter sets, a ragged batch and a trajectory that ran out of steps."""
+    import subprocess
+    import sys
+    out = str(tmp_path / "adj.npz")
+    code = f"""
+import sys, numpy as np, torch
+sys.path.insert(0, {os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "hybrid-ode-for-glp-1-and-glucose_amd")!r})
+import hode
+g = np.load({os.path.join(golden_dir, "g4_t61_pulses.npz")!r}); w = np.load({os.path.join(golden_dir, "g0_weights_h64_l4.npz")!r})
+f = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.float32, device="cuda")
+x0 = f(np.concatenate([g["x0"]] * 6)[:42]); meal = f(np.concatenate([g["meal"]] * 6)[:42]); tv = f(np.concatenate([g["tvns"]] * 6)[:42])
+nn2 = torch.cat([f(w["nn_flat"]), 0.5 * f(w["nn_flat"])]); ode2 = torch.cat([f(w["ode"]), f(w["ode"])])
+s = hode.solve_fwd(x0, f(g["t"]), meal, tv, None, ode2, nn2, 64, 4, n_sets=2, want_tape=True)
+c = torch.randn(s.y.shape, device="cuda", generator=torch.Generator("cuda").manual_seed(4))
+gx0, gnn, gode = hode.solve_bwd(s, c, want_gode=True)
+gx0b, gnnb, _ = hode.solve_bwd(s, c)                                   # the tape can be walked again
+s1 = hode.solve_fwd(x0[:3], f(g["t"]), meal[:3], tv[:3], None, ode2[:17], nn2[:13510], 64, 4, want_tape=True, max_steps=45)
+g1x, g1n, _ = hode.solve_bwd(s1, c[:3])
+np.savez({out!r}, gx0=gx0.cpu().numpy(), gnn=gnn.cpu().numpy(), gode=gode.cpu().numpy(), gnnb=gnnb.cpu().numpy(),
+         st1=s1.status.cpu().numpy(), g1x=g1x.cpu().numpy(), g1n=g1n.cpu().numpy())
+"""
+    res = {}
+    for mode in ("split", "fused"):
+        env = dict(os.environ, HODE_BWD=mode)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[mode] = dict(np.load(out))
+    a, b = res["split"], res["fused"]
+    assert relnorm(a["gx0"], b["gx0"]) < 1e-5 and relnorm(a["gnn"], b["gnn"]) < 1e-5 and relnorm(a["gode"], b["gode"]) < 1e-4
+    assert relnorm(a["gnnb"], a["gnn"]) < 1e-5
+    assert (a["st1"] == 1).any() and relnorm(a["g1x"], b["g1x"]) < 1e-5 and relnorm(a["g1n"], b["g1n"]) < 1e-5
+    # and against the oracle (fp64 at tight tolerances): the 1e-4 bar of north_star
+    g = np.load(os.path.join(golden_dir, "g4_t61_pulses.npz"))
+    xs, ms, vs = (np.concatenate([g[k]] * 6)[:21] for k in ("x0", "meal", "tvns"))
+    ref = O.solve(xs, g["t"], ms, vs, None, g0["ode"], g0["nn"], 64, 4, rtol=1e-10, atol=1e-12, dtype=np.float64, want_tape=True)
+    c = torch.randn(42, 61, 6, device="cuda", generator=torch.Generator("cuda").manual_seed(4)).cpu().numpy()[:21]
+    rx, rnn, rode = O.solve_bwd(ref, c.astype(np.float64))
+    assert relnorm(a["gnn"][:13510], rnn) < 1e-4 and relnorm(a["gx0"][:21], rx) < 1e-4 and relnorm(a["gode"][:17], rode) < 1e-3
