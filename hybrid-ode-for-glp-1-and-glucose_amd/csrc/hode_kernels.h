@@ -102,12 +102,13 @@ inline size_t tape_stage_offset(int B, int max_steps, size_t elem)
 // reals per stage record: h_1..h_L (tuned path: L rows of 64; generic path: 2 L rows, two hidden units per lane) + 8 for the
 // stage state
 inline size_t tape_slot_elems(int H, int L) { return (size_t)(tuned_shape(H, L) ? L : 2 * L) * 64 + 8; }
-// The split adjoint of the tuned fp32 path (hode_solve_bwd_split.hip) hands the layer cotangents of every stage from its
-// propagation kernel to its accumulation kernel through HBM: delta_1..delta_L (L rows of 64) + {kb[6], t, tVNS} in 8 reals per
-// stage, in a region of the tape behind the stage tape (the tape is the adjoint's workspace: nothing is allocated inside the
-// library).  Other dtypes / shapes have no such region.
+// The split adjoint of the tuned fp32 path (hode_solve_bwd_split.hip; opt-in, HODE_BWD=split) hands the layer cotangents of
+// every stage from its propagation kernel to its accumulation kernel through HBM: delta_1..delta_L (L rows of 64) + {kb[6], t,
+// tVNS} in 8 reals per stage, in a region of the tape behind the stage tape (the tape is the adjoint's workspace: nothing is
+// allocated inside the library).  Without the switch, and for other dtypes / shapes, there is no such region.
 inline size_t delta_slot_elems(int L) { return (size_t)L * 64 + 8; }
-inline bool has_delta_tape(size_t elem, int H, int L) { return elem == 4 && tuned_shape(H, L); }
+bool split_adjoint_enabled();       // HODE_BWD=split (hode_solve_bwd.hip); the default is the fused one-kernel adjoint
+inline bool has_delta_tape(size_t elem, int H, int L) { return elem == 4 && tuned_shape(H, L) && L >= 2 && split_adjoint_enabled(); }
 inline size_t tape_delta_offset(int B, int max_steps, size_t elem, int H, int L)
 {
     size_t o = tape_stage_offset(B, max_steps, elem) + (size_t)B * max_steps * 6 * tape_slot_elems(H, L) * elem;

@@ -1,22 +1,25 @@
-// hode_solve_bwd_split.hip -- K4 for the tuned fp32 path as TWO kernels (the fused kernel of hode_solve_bwd.hip stays for
-// fp64, for HODE_BWD=fused and as the reference the split is tested against).
+// hode_solve_bwd_split.hip -- K4 for the tuned fp32 path as TWO kernels: an EXPERIMENT (HODE_BWD=split), not the default.
 //
-// The fused adjoint keeps 192 gradient accumulators in registers, so the transposed matrices it needs for delta_{l-1} =
-// W_l^T delta_l have to come from LDS: 48 KB of ds_read_b128 per stage and per wave, at 2 waves per SIMD.  Its stage time
-// (2 920 cycles per SIMD) is 1 455 cycles of DPP FMAs, ~900 of other VALU and ~550 of waits, most of them on that LDS
-// traffic.  Splitting the work by what it needs:
+// The fused adjoint (hode_solve_bwd.hip) keeps 192 gradient accumulators in registers, so the transposed matrices it needs
+// for delta_{l-1} = W_l^T delta_l have to come from LDS: 48 KB of ds_read_b128 per stage and per wave, at 2 waves per SIMD.
+// Its stage time (2 920 cycles per SIMD) is 1 455 cycles of DPP FMAs, ~900 of other VALU and ~550 of waits.  The idea here:
 //
 //   A  solve_bwd_prop_kernel   reverse sweep proper: lambda, kb, mechanistic J^T, delta propagation.  No parameter-gradient
 //                              accumulators, so the transposed matrices live in REGISTERS (192, same rotating-operand
-//                              order as the forward): the kernel has the forward's shape -- no LDS weight traffic, no
-//                              barrier.  It writes what the gradients need, per stage, to the "delta tape":
-//                              delta_1 .. delta_L (rows of 64) | kb[6], t, tVNS.
+//                              order as the forward): the kernel has the forward's shape and instruction count (333 VALU
+//                              per stage, 180 of them DPP FMAs).  It writes what the gradients need, per stage, to the
+//                              "delta tape": delta_1 .. delta_L (rows of 64) | kb[6], t, tVNS.
 //   B  solve_bwd_accum_kernel  a streaming reduction over all (trajectory, step, stage) records:
 //                              dW_l += delta_l (x) h_{l-1} (64 v_fmac_f32_dpp per matrix, accumulators in registers),
-//                              first / last layer and bias gradients.  Both tapes arrive by LDS-DMA one record ahead.
+//                              first / last layer and bias gradients.  Both tapes arrive by LDS-DMA, three records ahead.
 //
-// Cost: the layer cotangents cross HBM once more (1 056 B per stage written by A and read by B, next to the 1 056 B of
-// activations both read).  At 288 GB / 8 TB/s that is the cheap resource here.
+// MEASURED (MI355X, 4 096 x 241, fp32): A 5.5 ms + B 3.3 ms = 8.8 ms against 8.0 ms for the fused kernel, identical
+// gradients (tests/test_hip_parity.py::test_split_adjoint_matches_the_fused_adjoint).  A runs the forward's instruction
+// count 30 % slower than the forward (every stage starts with LDS reads of a DMA'd record); B, with nothing but outer
+// products, still needs 1 180 cycles per sample at 2 waves per SIMD.  The LDS reads the split removes were not where the
+// fused kernel's time goes, and the layer cotangents cross HBM twice more (+12 GB per step).  Lessons kept in the code:
+// vmcnt retires in issue order, so (i) record DMAs must be waited for with a COUNT that leaves the younger delta stores
+// in flight, (ii) with stages this short the DMA ring has to run three records ahead.
 #include "hode_device.h"
 #include "hode_kernels.h"
 #include <cstdlib>
@@ -27,6 +30,10 @@ namespace {
 
 constexpr int kPropWaves = 4;       // waves per workgroup of kernel A (2 workgroups per CU: 2 waves per SIMD)
 constexpr int kAccWaves = 8;        // waves per workgroup of kernel B (1 workgroup per CU)
+// records in flight ahead of the one being processed (LDS-DMA rings of kAhead + 1 slots).  A stage of kernel A is ~1 300
+// cycles, a sample of kernel B ~800: one record ahead is less lead than the loaded-HBM latency
+constexpr int kAhead = 3;
+constexpr int kRing = kAhead + 1;
 
 template <typename R> __device__ __forceinline__ R inp_at_s(const R *__restrict__ p, int mode, int b, int T, int k)
 {
@@ -63,14 +70,20 @@ __device__ __forceinline__ float rhs_vjp_prop(const float (&w1)[9], const float 
     d = rfma(w5[4], lGE, d);
     d = rfma(w5[5], lF, d);
     d = (acts.h[NL - 1] > 0.f) ? d : 0.f;
+#ifndef HODE_EXPERIMENT_NO_DSTORE
     drec[(NL - 1) * kWave + lane] = d;                               // delta_NL
+#endif
 #pragma unroll
     for (int l = NL - 1; l >= 1; --l) {                              // hidden matrix l-1 maps h_l -> h_{l+1}
         const float dp = wt.mul(l - 1, lane, d);
         d = (acts.h[l - 1] > 0.f) ? dp : 0.f;
+#ifndef HODE_EXPERIMENT_NO_DSTORE
         drec[(l - 1) * kWave + lane] = d;                            // delta_l
+#endif
     }
+#ifndef HODE_EXPERIMENT_NO_DSTORE
     if (lane < 8) drec[NL * kWave + lane] = (lane < 6) ? kb : (lane == 6) ? t : tvns;
+#endif
     float p[6];
     p[0] = w1[1] * d;
     p[1] = w1[2] * d;
@@ -90,7 +103,7 @@ __global__ __launch_bounds__(64 * kPropWaves, 2) void solve_bwd_prop_kernel(cons
     constexpr int kSlot = kRows * kWave + 8;          // stage record (forward) and delta record (this kernel): same shape
     constexpr int kBuf = kRows * kWave + kWave;
     __shared__ R rowsT[8 * kWave];
-    __shared__ R recs[kPropWaves * 2 * kBuf];
+    __shared__ R recs[kPropWaves * kRing * kBuf];
     const int lane = threadIdx.x & 63;
     const int c8 = lane & 7, grp = lane >> 3;
     const int wave = first_lane((int)(threadIdx.x >> 6));
@@ -100,7 +113,7 @@ __global__ __launch_bounds__(64 * kPropWaves, 2) void solve_bwd_prop_kernel(cons
     const TableauData &tab = kTableau[method];
     const int S = tab.S;
     const R *__restrict__ nn_set = a.nn_p + (size_t)set * a.P;
-    R *rec = recs + (size_t)wave * 2 * kBuf;
+    R *rec = recs + (size_t)wave * kRing * kBuf;
 
     tableau_rowsT_store<R>(rowsT, method, threadIdx.x, 64 * kPropWaves);
     OdeP<R> o;
@@ -133,8 +146,23 @@ __global__ __launch_bounds__(64 * kPropWaves, 2) void solve_bwd_prop_kernel(cons
         const bool ok = a.status[b] == HODE_ST_OK;
         R lam = 0.f;
         int knext = T - 1, cur = 0;
-        bool first = true;                                    // no delta stores behind the first record's DMA yet
-        if (n > 0) record_dma(stg + ((size_t)(n - 1) * 6 + (S - 1)) * kSlot, rec, kRows, lane);
+        // records are consumed in the order (n-1, S-1), (n-1, S-2), ..., (0, 0); (pst, ps) walks kAhead records ahead.
+        // vmcnt retires in issue order.  Behind the DMA of record i (issued at the top of stage i - kAhead) come, in steady
+        // state, kAhead groups of NL + 1 delta stores and kAhead - 1 younger record DMAs of NL + 1 instructions each:
+        // "at most that many outstanding" == record i has landed.  Outside the steady state (head and tail of a trajectory)
+        // fewer operations follow and the same count would not prove it: those stages drain.
+        constexpr int kYounger = (2 * kAhead - 1) * (NL + 1);
+        static_assert(kYounger < 64, "vmcnt field");
+        constexpr int kWaitSteady = 0x0f70 | (kYounger & 15) | ((kYounger >> 4) << 14);
+        const int Ntot = n * S;
+        int pst = n - 1, ps = S - 1, issued = 0, idx = 0;
+        auto issue_next = [&]() {
+            if (pst < 0) return;
+            record_dma(stg + ((size_t)pst * 6 + ps) * kSlot, rec + (issued % kRing) * kBuf, kRows, lane);
+            ++issued;
+            if (--ps < 0) { ps = S - 1; --pst; }
+        };
+        for (int j = 0; j < kAhead; ++j) issue_next();
 #pragma unroll 1
         for (int st = n - 1; st >= 0; --st) {
             const int kraw = tseg[st];
@@ -165,21 +193,20 @@ __global__ __launch_bounds__(64 * kPropWaves, 2) void solve_bwd_prop_kernel(cons
             R ZZ = 0.f;
 #pragma unroll 1
             for (int s = S - 1; s >= 0; --s) {
-                // The record DMA of this stage was issued one stage ago and is OLDER than the NL + 1 delta stores issued
-                // after it: vmcnt retires in order, so "at most NL + 1 outstanding" means the record has landed while the
-                // stores may still be in flight.  (With FEWER than NL + 1 younger operations -- the first stage of a
-                // trajectory -- the same count could leave part of the DMA outstanding: that stage drains.)
-                if (first) __builtin_amdgcn_s_waitcnt(0x0f70);
-                else __builtin_amdgcn_s_waitcnt(0x0f70 | (NL + 1));
-                first = false;
+#ifdef HODE_EXPERIMENT_NO_DSTORE
+                __builtin_amdgcn_s_waitcnt(0x0f70);
+#else
+                if (idx >= kAhead && idx + kAhead - 1 < Ntot) __builtin_amdgcn_s_waitcnt(kWaitSteady);
+                else __builtin_amdgcn_s_waitcnt(0x0f70);
+#endif
                 __builtin_amdgcn_wave_barrier();
-                const int nst = (s > 0) ? st : st - 1, ns_ = (s > 0) ? s - 1 : S - 1;
-                if (nst >= 0) record_dma(stg + ((size_t)nst * 6 + ns_) * kSlot, rec + (cur ^ 1) * kBuf, kRows, lane);
+                issue_next();                                  // record idx + kAhead -> the slot consumed one stage ago
+                ++idx;
                 MlpActs<R, NL> ac;
 #pragma unroll
                 for (int l = 0; l < NL; ++l) ac.h[l] = rec[cur * kBuf + l * kWave + lane];
                 const R Ys = rec[cur * kBuf + kRows * kWave + c8];
-                cur ^= 1;
+                cur = (cur + 1) % kRing;
                 const R bw_s = rowsT[6 * kWave + s], c_s = rowsT[6 * kWave + 8 + s];
                 const R kb = h * rfma(bw_s, lam, group_sum8(rowsT[s * kWave + lane] * ZZ));
                 const R ts = rfma(c_s, h, tc);
@@ -224,13 +251,13 @@ __global__ __launch_bounds__(64 * kAccWaves, 2) void solve_bwd_accum_kernel(cons
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     R *red = reinterpret_cast<R *>(smem_raw);                            // [(NL-1)][64][64] cross-wave sum of the hidden matrices
     R *redE = red + (kHid > 0 ? kHid : 1);                               // [slots][64] cross-wave sum of the edge parameters
-    R *recs = redE + ES::count * kWave;                                  // [waves][2 (h | delta)][2][kBuf]
+    R *recs = redE + ES::count * kWave;                                  // [waves][2 (h | delta)][kRing][kBuf]
     const int lane = threadIdx.x & 63;
     const int wave = first_lane((int)(threadIdx.x >> 6));
     const int set = blockIdx.y;
     const int per_set = a.B / a.n_sets;
     const int S = kTableau[method].S;
-    R *hbuf = recs + (size_t)wave * 4 * kBuf, *dbuf = hbuf + 2 * kBuf;
+    R *hbuf = recs + (size_t)wave * 2 * kRing * kBuf, *dbuf = hbuf + kRing * kBuf;
     const int p16 = lane & 15;
 
     R gwh[(NL > 1) ? NL - 1 : 1][kMaxH];
@@ -248,19 +275,27 @@ __global__ __launch_bounds__(64 * kAccWaves, 2) void solve_bwd_accum_kernel(cons
         const R *__restrict__ dtp = a.tape_delta + (size_t)b * a.max_steps * 6 * kSlot;
         const int n = a.nsteps[b] < a.max_steps ? a.nsteps[b] : a.max_steps;
         const int N = n * S;                                  // records of this trajectory, any order: (i / S, i % S)
-        int cur = 0;
-        if (N > 0) { record_dma(stg, hbuf, kRows, lane); record_dma(dtp, dbuf, kRows, lane); }
-        int st = 0, s = 0;                                    // record i = (st, s); the DMA runs one record ahead
+        // both records of sample i sit in ring slot i % kRing; the DMAs run kAhead samples ahead.  Only DMAs are in flight
+        // here (2 (NL + 1) instructions per sample), in issue order: with the kAhead - 1 younger samples still allowed
+        // outstanding, sample i has landed
+        constexpr int kYounger = (kAhead - 1) * 2 * (NL + 1);
+        static_assert(kYounger < 64, "vmcnt field");
+        constexpr int kWaitSteady = 0x0f70 | (kYounger & 15) | ((kYounger >> 4) << 14);
+        int cur = 0, pst = 0, ps = 0, issued = 0;
+        auto issue_next = [&]() {
+            if (issued >= N) return;
+            record_dma(stg + ((size_t)pst * 6 + ps) * kSlot, hbuf + (issued % kRing) * kBuf, kRows, lane);
+            record_dma(dtp + ((size_t)pst * 6 + ps) * kSlot, dbuf + (issued % kRing) * kBuf, kRows, lane);
+            ++issued;
+            if (++ps == S) { ps = 0; ++pst; }
+        };
+        for (int j = 0; j < kAhead; ++j) issue_next();
 #pragma unroll 1
         for (int i = 0; i < N; ++i) {
-            __builtin_amdgcn_s_waitcnt(0x0f70);               // vmcnt(0): both records of sample i have landed
+            if (i + kAhead - 1 < N) __builtin_amdgcn_s_waitcnt(kWaitSteady);
+            else __builtin_amdgcn_s_waitcnt(0x0f70);          // tail: fewer younger DMAs than the count assumes
             __builtin_amdgcn_wave_barrier();
-            int nst = st, ns_ = s + 1;
-            if (ns_ == S) { ns_ = 0; ++nst; }
-            if (i + 1 < N) {
-                record_dma(stg + ((size_t)nst * 6 + ns_) * kSlot, hbuf + (cur ^ 1) * kBuf, kRows, lane);
-                record_dma(dtp + ((size_t)nst * 6 + ns_) * kSlot, dbuf + (cur ^ 1) * kBuf, kRows, lane);
-            }
+            issue_next();                                     // sample i + kAhead -> the slot consumed one sample ago
             const R *__restrict__ hr = hbuf + cur * kBuf, *__restrict__ dr = dbuf + cur * kBuf;
             // hidden matrices: dW_l += delta_{l+2} (x) h_{l+1}  (rows l+1 of the delta record, l of the activation record)
 #pragma unroll
@@ -290,8 +325,7 @@ __global__ __launch_bounds__(64 * kAccWaves, 2) void solve_bwd_accum_kernel(cons
 #pragma unroll
             for (int q = 0; q < 6; ++q) ge[ES::w5 + q] = rfma(ts[q], hl, ge[ES::w5 + q]);
             ge[ES::b5] += ts[lane & 7];                        // lanes 0..5 hold dbout (slots 6, 7 carry t / tVNS: never flushed)
-            cur ^= 1;
-            st = nst; s = ns_;
+            cur = (cur + 1) % kRing;
         }
     }
 
@@ -334,7 +368,7 @@ __global__ __launch_bounds__(64 * kAccWaves, 2) void solve_bwd_accum_kernel(cons
 template <int NL> constexpr size_t accum_lds_bytes()
 {
     constexpr size_t hid = (NL > 1 ? NL - 1 : 0) * (size_t)kMaxH * kMaxH;
-    return ((hid > 0 ? hid : 1) + EdgeSlots<NL>::count * kWave + (size_t)kAccWaves * 4 * (NL * kWave + kWave)) * sizeof(float);
+    return ((hid > 0 ? hid : 1) + EdgeSlots<NL>::count * kWave + (size_t)kAccWaves * 2 * kRing * (NL * kWave + kWave)) * sizeof(float);
 }
 
 template <int NL, bool GODE, bool GD> int launch_split_g(hipStream_t s, const AdjArgs<float> &a, int method)

@@ -64,9 +64,9 @@ class _RhsFn(torch.autograd.Function):
         return gx, gt, gnn, gode, None, None, None, None, None
 
 
-# Stage-tape budget of one autograd solve.  Activations + layer cotangents: 2 x 6*(L*256 + 32) B per accepted step (3.8 MB per trajectory
-# for the 4x64 network at T = 241): 4 096 patients need 14.5 GiB, BASELINE config 5's 8 192 patients x 16 VI samples per
-# GPU would need 465 GiB.  Above the budget the forward runs WITHOUT a tape and the backward re-integrates the batch in
+# Stage-tape budget of one autograd solve.  The adjoint reads 6*(L*256 + 32) B per accepted step (1.9 MB per trajectory
+# for the 4x64 network at T = 241): 4 096 patients need 7.3 GiB, BASELINE config 5's 8 192 patients x 16 VI samples per
+# GPU would need 233 GiB.  Above the budget the forward runs WITHOUT a tape and the backward re-integrates the batch in
 # chunks that fit (forward-with-tape + adjoint per chunk, one tape buffer re-used): bounded memory for 1.3x the time.
 TAPE_BUDGET_BYTES = 64 << 30
 

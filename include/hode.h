@@ -119,10 +119,9 @@ int hode_solve_fwd_f64(void *stream, int B, int T, const double *x0, const doubl
 /* ---- K4: reverse-time discrete adjoint of the solve above (no reference counterpart: the
  *      reference detaches the solve; north_star requires it).
  *      gy[B,T,6] = dLoss/dy  ->  gx0[B,6] (written), gnn[n_sets,P] and gode[n_sets,17]
- *      (ACCUMULATED with atomics: zero them first; either may be NULL).  tape: the buffer the forward filled; its tail
- *      (fp32, H <= 64, L <= 4) is the adjoint's scratch -- the layer cotangents travel through it from the propagation
- *      kernel to the accumulation kernel -- so the tape is not const here; what the forward recorded stays intact
- *      (the same tape may be walked again).                                                      */
+ *      (ACCUMULATED with atomics: zero them first; either may be NULL).  tape: the buffer the forward filled.  It is not
+ *      const: with HODE_BWD=split (an experimental two-kernel adjoint) its tail is scratch for the layer cotangents;
+ *      what the forward recorded stays intact, the same tape may be walked again.                 */
 int hode_solve_bwd_f32(void *stream, int B, int T, const float *t, int t_batched,
                        const float *meal, int meal_mode, const float *tvns, int tvns_mode,
                        const float *gd, int gd_mode, const float *ode_p, const float *nn_p,

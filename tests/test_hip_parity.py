@@ -619,10 +619,10 @@ np.savez({out!r}, y=a.y.cpu().numpy(), yt=b.y.cpu().numpy(), nfev=a.nfev.cpu().n
 
 
 def test_split_adjoint_matches_the_fused_adjoint(hode, golden_dir, g0, tmp_path):
-    """fp32 production adjoint = two kernels (propagation with W^T in registers -> delta tape -> accumulation;
-    csrc/hode_solve_bwd_split.hip).  HODE_BWD=fused runs the one-kernel adjoint of hode_solve_bwd.hip on the same tape:
-    same gradients up to summation order (both against the fp64 oracle as well), including ODE-constant gradients, two
-    parameter sets, a ragged batch and a trajectory that ran out of steps."""
+    """HODE_BWD=split runs the adjoint as two kernels (propagation with W^T in registers -> delta tape -> accumulation;
+    csrc/hode_solve_bwd_split.hip, an experiment that measured slower than the default one-kernel adjoint): same gradients
+    up to summation order (both against the fp64 oracle as well), including ODE-constant gradients, two parameter sets, a
+    ragged batch and a trajectory that ran out of steps."""
     import subprocess
     import sys
     out = str(tmp_path / "adj.npz")

@@ -35,8 +35,8 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     assert hode.version().startswith("hode ")
     assert lib.hode_nn_param_count(64, 4) == 13510 and lib.hode_nn_param_count(32, 2) == 1574
-    # fp32 tuned shapes: entries + interval indices, the stage tape (h_1..h_4 + state per stage) and the split adjoint's delta tape
-    assert hode.load().hode_tape_bytes(4096, 300, 4, 4) == 4096 * 300 * 36 + 2 * 4096 * 300 * 6 * (4 * 64 + 8) * 4
+    # entries + interval indices + the stage tape (h_1..h_4 + state per stage); HODE_BWD=split adds a delta tape of the same size
+    assert hode.load().hode_tape_bytes(4096, 300, 4, 4) == 4096 * 300 * 36 + (2 if os.environ.get("HODE_BWD", "").startswith("s") else 1) * 4096 * 300 * 6 * (4 * 64 + 8) * 4
     assert hode.load().hode_tape_bytes(4096, 300, 8, 4) == 4096 * 300 * 68 + 4096 * 300 * 6 * (4 * 64 + 8) * 8      # fp64: no delta tape
     # the generic path (H > 64 or L > 4) records two rows of 64 per layer + the state: 2L x 64 + 8 reals per stage
     assert lib.hode_tape_bytes_hl(32, 92, 4, 128, 5) == 32 * 92 * 36 + 32 * 92 * 6 * (10 * 64 + 8) * 4
