@@ -44,7 +44,8 @@ def test_elbo_value_and_components_vs_reference(setup):
     draws = [m.variational_params.sample(1)[0] for _ in range(2)]
     for i, d in enumerate(draws):
         for n, v in d.items():
-            assert np.array_equal(v.detach().numpy(), g[f"draw{i}__{n}"]), n
+            # same RNG stream as the reference; exp(log_sigma) may differ in the last bit between host CPUs (vectorised libm)
+            np.testing.assert_allclose(v.detach().numpy(), g[f"draw{i}__{n}"], rtol=1e-6, atol=1e-9, err_msg=n)
         with torch.no_grad():
             y = m.forward_with_params({k: v.detach() for k, v in d.items()}, batch["initial_state"], batch["time_points"],
                                       batch["external_inputs"])
