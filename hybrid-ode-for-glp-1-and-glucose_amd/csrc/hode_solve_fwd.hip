@@ -54,17 +54,20 @@ static int launch_nl(hipStream_t s, const SolveArgs<R> &a, int method)
     return hipGetLastError() == hipSuccess ? HODE_OK : HODE_ELAUNCH;
 }
 
-// HODE_FWD=wg: the workgroup kernel (hode_solve_fwd_wg.hip) for comparison
-static bool fwd_use_wg()
+// HODE_FWD=wg: the LDS-image workgroup kernel (hode_solve_fwd_wg.hip); HODE_FWD=quad: four trajectories per four waves with
+// column-split weights (hode_solve_fwd_quad.hip); HODE_FWD=regs: this file's kernel
+static char fwd_mode()
 {
-    static const bool v = [] { const char *e = getenv("HODE_FWD"); return e && e[0] == 'w'; }();
+    static const char v = [] { const char *e = getenv("HODE_FWD"); return e ? e[0] : '\0'; }();
     return v;
 }
+static bool fwd_use_wg() { return fwd_mode() == 'w'; }
 
 template <typename R> int launch_solve_fwd(hipStream_t s, const SolveArgs<R> &a, int L, int method)
 {
     if constexpr (sizeof(R) == 4) {
         if (L >= 2 && L <= 4 && fwd_use_wg()) return launch_solve_fwd_wg(s, a, L, method);
+        if (L >= 2 && L <= 4 && fwd_mode() == 'q') return launch_solve_fwd_quad(s, a, L, method);
     }
     switch (L) {
     case 1: return launch_nl<R, 1>(s, a, method);

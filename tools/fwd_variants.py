@@ -1,12 +1,14 @@
 """Forward-kernel tuning points (development aid).  One process per variant (the environment switches are read once):
     (default)                          register-resident kernel (hode_solve_fwd.hip)
     HODE_FWD=wg HODE_FWD_CFG=<NREG><WPB/4>   workgroup kernel (hode_solve_fwd_wg.hip): 4, 22, default (14)
+    HODE_FWD=quad                      four trajectories per four waves, column-split weights (hode_solve_fwd_quad.hip)
 Usage: python tools/fwd_variants.py [B ...]   -> one line per batch size; the first run writes /tmp/fwd_ref_<B>.pt, later runs compare bitwise."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "hybrid-ode-for-glp-1-and-glucose_amd")); sys.path.insert(0, ROOT)
 import torch, hode, bench
-tag = "wg cfg " + os.environ.get("HODE_FWD_CFG", "default") if os.environ.get("HODE_FWD", "").startswith("w") else "regs"
+_m = os.environ.get("HODE_FWD", "")
+tag = "wg cfg " + os.environ.get("HODE_FWD_CFG", "default") if _m.startswith("w") else ("quad" if _m.startswith("q") else "regs")
 dev = torch.device("cuda")
 for B in [int(v) for v in sys.argv[1:]] or [4096]:
     x0, t, meal, tv = (v.to(dev) for v in bench.synth_cohort(B, 1000))
