@@ -1,11 +1,12 @@
-// hode_solve_fwd_quad.hip -- K2+K3, fp32: FOUR trajectories per workgroup of FOUR waves, hidden matrices split by columns.
+// hode_solve_fwd_quad.hip -- K2+K3, fp32 EXPERIMENT (HODE_FWD=quad): FOUR trajectories per workgroup of FOUR waves, hidden
+// matrices split by columns.  Bit-identical to the production kernel; measured no faster (see the end of this comment).
 //
-// What bounds the register-resident kernel (hode_solve_fwd.hip) is not the DPP FMA rate but the issue cadence of a single
-// wave: measured (tools/ubench/bank_ubench.hip, inst_cost_ubench.hip) a wave issues one VALU instruction every ~7.5 cycles
-// whatever the instruction, so a SIMD needs FOUR resident waves to reach ~2 cycles per instruction -- v_fmac_f32_dpp
-// included (1.96 cycles at 4 waves per SIMD, 3.72 at 2, 5.6 at 1).  211 weight registers allow two.  Reading the weights
-// from an LDS image instead (hode_solve_fwd_wg.hip) buys the occupancy and loses it again to the LDS pipe: 48 KB of reads
-// per RHS and wave.
+// The idea.  Micro-benchmarks (tools/ubench/bank_ubench.hip, inst_cost_ubench.hip) say a single wave issues one VALU
+// instruction every ~7.5 cycles whatever the instruction, and a SIMD reaches ~2 cycles per instruction only with FOUR
+// resident waves -- v_fmac_f32_dpp included (1.96 cycles at 4 waves per SIMD, 3.72 at 2, 5.6 at 1: the DPP FMA is not
+// "half rate", it is the occupancy that is missing).  211 weight registers allow two waves.  Reading the weights from an
+// LDS image instead (hode_solve_fwd_wg.hip) buys the occupancy and loses it again to the LDS pipe: 48 KB of reads per RHS
+// and wave.
 //
 // Here the four waves of a workgroup integrate four trajectories and SHARE the weights by columns: wave w keeps, of every
 // hidden matrix, the 16 columns 16w .. 16w+15 (48 registers for three matrices, in the rotating-operand order of
@@ -15,8 +16,8 @@
 //     2. the partial sums for the three trajectories they do not own (3 x 256 B each),
 // 2 KB written and 1.75 KB read per wave instead of 16 KB, two workgroup barriers.  Everything else -- first / last layer,
 // mechanistic terms, Runge-Kutta algebra, step-size control, output staging -- stays private to the wave that owns the
-// trajectory (solve_one, hode_solve_body.h).  ~125 VGPRs: four waves per SIMD, one workgroup of four trajectories per
-// SIMD-quartet; the 4 096-patient batch is 1 024 workgroups = 4 per CU.
+// trajectory (solve_one, hode_solve_body.h).  128 VGPRs, no scratch: four waves per SIMD; the 4 096-patient batch is
+// 1 024 workgroups = 4 per CU.
 //
 // The partial sums are combined in the order of the register kernel's four accumulators, (P0 + P1) + (P2 + P3), bias in
 // P0: results are BIT-IDENTICAL to hode_solve_fwd.hip (tests/test_hip_parity.py).
@@ -24,8 +25,15 @@
 // Lock step.  A layer needs all four waves, so the four trajectories evaluate their right-hand sides in rounds: every RHS
 // evaluation is one round = a flag exchange (who is still integrating) + NL - 1 layer exchanges.  A wave whose trajectory
 // has finished (or that has none: ragged last workgroup) keeps serving rounds with a zero activation until all four flags
-// are down; all waves leave together.  Adaptive step counts differ by a few per cent between patients of a cohort: that
-// is the price (the benchmark cohort takes one step per interval everywhere).
+// are down; all waves leave together.
+//
+// MEASURED (MI355X, fp32, T = 241): 4.40 ms at 4 096 trajectories against 4.13 for the register kernel, 7.96 ms at 8 192
+// against 7.96 -- the SAME 1.03 M trajectories/s at twice the occupancy; a lone trajectory takes 1.8x longer (seven
+// barriers per RHS).  Starting the workgroups of a CU a fraction of a round apart changes nothing.  Three structurally
+// different VALU-only kernels (registers at 2 waves per SIMD, LDS image at 4, column split at 4) end at the same
+// ~1.0 M trajectories/s, i.e. ~3.8 cycles per VALU instruction and SIMD at the ~2.3 GHz the chip holds: the ceiling is
+// not occupancy, LDS or the DPP rate of one of them but what they share -- ~550 instructions (363 VALU) per RHS and wave
+// through the same instruction front end.
 #include "hode_solve_body.h"
 #include <cstdlib>
 
@@ -154,7 +162,6 @@ __global__ __launch_bounds__(64 * kQuad, kQuad) void solve_fwd_quad_kernel(const
     OdeP<float> o;
     ode_load(o, a.ode_p + 17 * set);
     __syncthreads();
-
     const int bi = blockIdx.x * kQuad + wave;
     if (bi < per_set) {
         const RhsQuad<NL> rhs{W, o, lane};

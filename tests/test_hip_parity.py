@@ -581,7 +581,7 @@ def test_cfg4_65536_cohort_and_its_8_rank_shards(hode):
         assert torch.equal(shard.y, full.y[lo:hi])
 
 
-def test_fwd_workgroup_kernel_is_bitwise_the_register_kernel(hode, golden_dir, g0, tmp_path):
+def test_fwd_experiment_kernels_are_bitwise_the_register_kernel(hode, golden_dir, g0, tmp_path):
     """HODE_FWD=wg (hidden matrices in a shared LDS image, 16 waves per workgroup; hode_solve_fwd_wg.hip) runs the same
     arithmetic in the same order as the production kernel: identical bits, with and without a tape, ragged batch,
     two parameter sets.  (The switch is read once per process, so the variant runs in a child process.)"""
@@ -603,13 +603,15 @@ gx0, gnn, _ = hode.solve_bwd(b, torch.ones_like(b.y))
 np.savez({out!r}, y=a.y.cpu().numpy(), yt=b.y.cpu().numpy(), nfev=a.nfev.cpu().numpy(), gnn=gnn.cpu().numpy())
 """
     ys = {}
-    for mode in ("regs", "wg"):
+    for mode in ("regs", "wg", "quad"):          # quad: four trajectories per four waves, column-split weights (hode_solve_fwd_quad.hip)
         env = dict(os.environ, HODE_FWD=mode)
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         ys[mode] = dict(np.load(out))
     for k in ("y", "yt", "nfev"):
         assert np.array_equal(ys["regs"][k], ys["wg"][k]), k
+        assert np.array_equal(ys["regs"][k], ys["quad"][k]), k
+    assert relnorm(ys["quad"]["gnn"], ys["regs"]["gnn"]) < 1e-5
     assert np.array_equal(ys["regs"]["y"], ys["regs"]["yt"])
     # the adjoint consumes the stage tape either kernel wrote: same tape, same gradient up to the atomics' summation order
     assert relnorm(ys["wg"]["gnn"], ys["regs"]["gnn"]) < 1e-5
