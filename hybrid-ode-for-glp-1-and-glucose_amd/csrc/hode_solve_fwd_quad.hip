@@ -1,12 +1,11 @@
 // hode_solve_fwd_quad.hip -- K2+K3, fp32 EXPERIMENT (HODE_FWD=quad): FOUR trajectories per workgroup of FOUR waves, hidden
 // matrices split by columns.  Bit-identical to the production kernel; measured no faster (see the end of this comment).
 //
-// The idea.  Micro-benchmarks (tools/ubench/bank_ubench.hip, inst_cost_ubench.hip) say a single wave issues one VALU
-// instruction every ~7.5 cycles whatever the instruction, and a SIMD reaches ~2 cycles per instruction only with FOUR
-// resident waves -- v_fmac_f32_dpp included (1.96 cycles at 4 waves per SIMD, 3.72 at 2, 5.6 at 1: the DPP FMA is not
-// "half rate", it is the occupancy that is missing).  211 weight registers allow two waves.  Reading the weights from an
-// LDS image instead (hode_solve_fwd_wg.hip) buys the occupancy and loses it again to the LDS pipe: 48 KB of reads per RHS
-// and wave.
+// The idea.  Micro-benchmarks (tools/ubench/inst_cost_ubench.hip) say a single wave issues one VALU instruction every
+// ~7.5 cycles whatever the instruction, so the cost of an instruction to the SIMD falls with occupancy: v_fmac_f32_dpp
+// 6.7 / 3.8 / 2.9 cycles at 1 / 2 / 4 waves per SIMD, plain v_fma_f32 6.8 / 2.8 / 1.9.  211 weight registers allow two
+// waves.  Reading the weights from an LDS image instead (hode_solve_fwd_wg.hip) buys the occupancy and loses it again to the
+// LDS pipe: 48 KB of reads per RHS and wave.
 //
 // Here the four waves of a workgroup integrate four trajectories and SHARE the weights by columns: wave w keeps, of every
 // hidden matrix, the 16 columns 16w .. 16w+15 (48 registers for three matrices, in the rotating-operand order of
