@@ -45,7 +45,7 @@ def test_elbo_value_and_components_vs_reference(setup):
     for i, d in enumerate(draws):
         for n, v in d.items():
             # same RNG stream as the reference; exp(log_sigma) may differ in the last bit between host CPUs (vectorised libm)
-            np.testing.assert_allclose(v.detach().numpy(), g[f"draw{i}__{n}"], rtol=1e-6, atol=1e-9, err_msg=n)
+            np.testing.assert_allclose(v.detach().numpy(), g[f"draw{i}__{n}"], rtol=1e-5, atol=1e-8, err_msg=n)
         with torch.no_grad():
             y = m.forward_with_params({k: v.detach() for k, v in d.items()}, batch["initial_state"], batch["time_points"],
                                       batch["external_inputs"])
