@@ -403,22 +403,67 @@ __device__ __forceinline__ void rows_replicate(float h, float (&R)[4])
     // 2 wait states between the swaps (VALU writes) and the first DPP read of R[] in the asm FMAs
     asm volatile("s_nop 1" : "+v"(R[0]), "+v"(R[1]), "+v"(R[2]), "+v"(R[3]));
 }
-template <int N> __device__ __forceinline__ void mlp_hidden_step(const float (&w)[kMaxH], const float (&R)[4], float (&acc)[4])
-{
-    acc[0] = fmac_ror<N>(acc[0], R[0], w[0 * 16 + N]);
-    acc[1] = fmac_ror<N>(acc[1], R[1], w[1 * 16 + N]);
-    acc[2] = fmac_ror<N>(acc[2], R[2], w[2 * 16 + N]);
-    acc[3] = fmac_ror<N>(acc[3], R[3], w[3 * 16 + N]);
-    if constexpr (N < 15) mlp_hidden_step<N + 1>(w, R, acc);
-}
+// ---- one hidden layer as ONE asm statement (fp32, weights in registers) ----------------------------------------------------
+// Written as 64 separate asm statements hipcc's hazard recognizer puts an s_nop between any two of them that touch the same
+// register (it assumes an opaque asm may have the dst_sel forwarding hazard and does not count other asm statements as wait
+// states): one s_nop per four FMAs, ~50 per right-hand side, and a wave issues one instruction per ~7 cycles whatever it is
+//  -- an s_nop costs what an FMA costs.  As one statement the layer is 75 instructions instead of 94:
+//     v_mov + s_nop 1 + v_permlane16_swap, 2 v_mov + s_nop 0 + 2 v_permlane32_swap     rows of h replicated (rows_replicate)
+//     v_fma + 3 v_mul                                                                  rotation 0, bias folded in
+//     60 v_fmac_f32_dpp                                                                rotations 1..15
+//     3 v_add                                                                          (a0 + a1) + (a2 + a3)
+// Hazards (the compiler pads nothing inside an asm): a VALU result needs 2 wait states before a v_permlane*_swap reads it
+// (the s_nops, as hipcc emits them for the builtins) and before a DPP operand reads it (the four rotation-0 instructions
+// stand between the swaps and the first DPP read); accumulators and weights are ordinary interlocked operands.
+#define HODE_MV_ROW(n) \
+    "v_fmac_f32_dpp %[a0], %[r0], %[w0_" #n "] row_ror:" #n " row_mask:0xf bank_mask:0xf\n\t" \
+    "v_fmac_f32_dpp %[a1], %[r1], %[w1_" #n "] row_ror:" #n " row_mask:0xf bank_mask:0xf\n\t" \
+    "v_fmac_f32_dpp %[a2], %[r2], %[w2_" #n "] row_ror:" #n " row_mask:0xf bank_mask:0xf\n\t" \
+    "v_fmac_f32_dpp %[a3], %[r3], %[w3_" #n "] row_ror:" #n " row_mask:0xf bank_mask:0xf\n\t"
+#define HODE_MV_ROWS_1_15 \
+    HODE_MV_ROW(1) HODE_MV_ROW(2) HODE_MV_ROW(3) HODE_MV_ROW(4) HODE_MV_ROW(5) HODE_MV_ROW(6) HODE_MV_ROW(7) HODE_MV_ROW(8) \
+    HODE_MV_ROW(9) HODE_MV_ROW(10) HODE_MV_ROW(11) HODE_MV_ROW(12) HODE_MV_ROW(13) HODE_MV_ROW(14) HODE_MV_ROW(15)
+#define HODE_MV_W(n) [w0_##n] "v"(w[n]), [w1_##n] "v"(w[16 + n]), [w2_##n] "v"(w[32 + n]), [w3_##n] "v"(w[48 + n])
+#define HODE_MV_WEIGHTS \
+    HODE_MV_W(0), HODE_MV_W(1), HODE_MV_W(2), HODE_MV_W(3), HODE_MV_W(4), HODE_MV_W(5), HODE_MV_W(6), HODE_MV_W(7), HODE_MV_W(8), \
+    HODE_MV_W(9), HODE_MV_W(10), HODE_MV_W(11), HODE_MV_W(12), HODE_MV_W(13), HODE_MV_W(14), HODE_MV_W(15)
+// bias + sum_k W[j][k] h_k with w[16 q + n] on lane j = W[j][16 q + ((j - n) & 15)]
 __device__ __forceinline__ float mlp_hidden(const float (&w)[kMaxH], float bias, float h)
 {
-    float R[4];
-    rows_replicate(h, R);
-    float acc[4] = {bias, 0.f, 0.f, 0.f};
-    mlp_hidden_step<0>(w, R, acc);
-    return (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    float r0 = h, r1, r2, r3, a0, a1, a2, a3;
+    asm("v_mov_b32 %[r1], %[r0]\n\t"
+        "s_nop 1\n\t"
+        "v_permlane16_swap_b32 %[r0], %[r1]\n\t"          // r0 = [h0 h0 h2 h2]   r1 = [h1 h1 h3 h3]   (16-lane rows of h)
+        "v_mov_b32 %[r2], %[r0]\n\t"
+        "v_mov_b32 %[r3], %[r1]\n\t"
+        "s_nop 0\n\t"
+        "v_permlane32_swap_b32 %[r0], %[r2]\n\t"          // r0 = h0 x 4, r2 = h2 x 4
+        "v_permlane32_swap_b32 %[r1], %[r3]\n\t"          // r1 = h1 x 4, r3 = h3 x 4
+        "v_fma_f32 %[a0], %[r0], %[w0_0], %[bias]\n\t"
+        "v_mul_f32 %[a1], %[r1], %[w1_0]\n\t"
+        "v_mul_f32 %[a2], %[r2], %[w2_0]\n\t"
+        "v_mul_f32 %[a3], %[r3], %[w3_0]\n\t"
+        HODE_MV_ROWS_1_15
+        "v_add_f32 %[a0], %[a0], %[a1]\n\t"
+        "v_add_f32 %[a2], %[a2], %[a3]\n\t"
+        "v_add_f32 %[a0], %[a0], %[a2]"
+        : [r0] "+v"(r0), [r1] "=&v"(r1), [r2] "=&v"(r2), [r3] "=&v"(r3), [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2), [a3] "=&v"(a3)
+        : [bias] "v"(bias), HODE_MV_WEIGHTS);
+    return a0;
 }
+// acc[q] += sum_n row_ror:n(R[q]) * w[16 q + n], n ascending within each accumulator; R[] must be two wait states old
+__device__ __forceinline__ void rot_matvec64(const float (&w)[kMaxH], const float (&R)[4], float (&acc)[4])
+{
+    asm("v_fmac_f32 %[a0], %[r0], %[w0_0]\n\tv_fmac_f32 %[a1], %[r1], %[w1_0]\n\t"
+        "v_fmac_f32 %[a2], %[r2], %[w2_0]\n\tv_fmac_f32 %[a3], %[r3], %[w3_0]\n\t"
+        HODE_MV_ROWS_1_15
+        : [a0] "+v"(acc[0]), [a1] "+v"(acc[1]), [a2] "+v"(acc[2]), [a3] "+v"(acc[3])
+        : [r0] "v"(R[0]), [r1] "v"(R[1]), [r2] "v"(R[2]), [r3] "v"(R[3]), HODE_MV_WEIGHTS);
+}
+#undef HODE_MV_ROW
+#undef HODE_MV_ROWS_1_15
+#undef HODE_MV_W
+#undef HODE_MV_WEIGHTS
 __device__ __forceinline__ double mlp_hidden(const double (&w)[kMaxH], double bias, double h)
 {
     double acc0 = bias, acc1 = 0.0;
@@ -651,14 +696,6 @@ template <typename R> struct WtLds {
     const R *wt;
     __device__ __forceinline__ R mul(int l, int lane, R d) const { return wt_mul(wt + (size_t)l * kMaxH * kMaxH, lane, d); }
 };
-template <int N> __device__ __forceinline__ void wt_reg_step(const float (&w)[kMaxH], const float (&Rr)[4], float (&acc)[4])
-{
-    acc[0] = fmac_ror<N>(acc[0], Rr[0], w[0 * 16 + N]);
-    acc[1] = fmac_ror<N>(acc[1], Rr[1], w[1 * 16 + N]);
-    acc[2] = fmac_ror<N>(acc[2], Rr[2], w[2 * 16 + N]);
-    acc[3] = fmac_ror<N>(acc[3], Rr[3], w[3 * 16 + N]);
-    if constexpr (N < 15) wt_reg_step<N + 1>(w, Rr, acc);
-}
 template <int NL> struct WtRegs {
     float w[(NL > 1) ? NL - 1 : 1][kMaxH];     // w[l][16q+n] on lane k = W_l[16q + ((k - n) & 15)][k]
     __device__ __forceinline__ void load(const float *__restrict__ nn_p, int H, int lane)
@@ -682,7 +719,7 @@ template <int NL> struct WtRegs {
         rows_replicate(d, Rr);
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
         // l is a compile-time constant at every call site (unrolled layer loop)
-        wt_reg_step<0>(w[l], Rr, acc);
+        rot_matvec64(w[l], Rr, acc);
         return (acc[0] + acc[1]) + (acc[2] + acc[3]);
     }
 };
@@ -725,23 +762,29 @@ __device__ __forceinline__ void layer_bwd_group(float (&gw)[kMaxH], const Vec4<f
     gw[3 * 16 + n + 3] = fmac_ror<n + 3>(gw[3 * 16 + n + 3], Rh[3], d);
     __builtin_amdgcn_sched_barrier(0);          // (hipcc otherwise hoists the dependent FMAs right behind the reads;
                                                 //  a two-deep pipeline of groups was tried: 32 more live registers spill)
-    // rows 4G..4G+3 of the image: r = 16 G + 4 i + c  ->  q = G, n = 4 i + c
-    acc[0] = fmac_ror<0>(acc[0], Rd[G], w0.v[0]);
-    acc[1] = fmac_ror<1>(acc[1], Rd[G], w0.v[1]);
-    acc[2] = fmac_ror<2>(acc[2], Rd[G], w0.v[2]);
-    acc[3] = fmac_ror<3>(acc[3], Rd[G], w0.v[3]);
-    acc[0] = fmac_ror<4>(acc[0], Rd[G], w1.v[0]);
-    acc[1] = fmac_ror<5>(acc[1], Rd[G], w1.v[1]);
-    acc[2] = fmac_ror<6>(acc[2], Rd[G], w1.v[2]);
-    acc[3] = fmac_ror<7>(acc[3], Rd[G], w1.v[3]);
-    acc[0] = fmac_ror<8>(acc[0], Rd[G], w2.v[0]);
-    acc[1] = fmac_ror<9>(acc[1], Rd[G], w2.v[1]);
-    acc[2] = fmac_ror<10>(acc[2], Rd[G], w2.v[2]);
-    acc[3] = fmac_ror<11>(acc[3], Rd[G], w2.v[3]);
-    acc[0] = fmac_ror<12>(acc[0], Rd[G], w3.v[0]);
-    acc[1] = fmac_ror<13>(acc[1], Rd[G], w3.v[1]);
-    acc[2] = fmac_ror<14>(acc[2], Rd[G], w3.v[2]);
-    acc[3] = fmac_ror<15>(acc[3], Rd[G], w3.v[3]);
+    // rows 4G..4G+3 of the image: r = 16 G + 4 i + c  ->  q = G, n = 4 i + c.  ONE asm statement: between separate
+    // statements that share an accumulator hipcc inserts an s_nop (see mlp_hidden above)
+    static_assert(G >= 0 && G < 4, "four groups of sixteen rotations");
+    asm("v_fmac_f32 %[a0], %[r], %[w0]\n\t"
+        "v_fmac_f32_dpp %[a1], %[r], %[w1] row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %[a2], %[r], %[w2] row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %[a3], %[r], %[w3] row_ror:3 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %[a0], %[r], %[w4] row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %[a1], %[r], %[w5] row_ror:5 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %[a2], %[r], %[w6] row_ror:6 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %[a3], %[r], %[w7] row_ror:7 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %[a0], %[r], %[w8] row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %[a1], %[r], %[w9] row_ror:9 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %[a2], %[r], %[w10] row_ror:10 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %[a3], %[r], %[w11] row_ror:11 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %[a0], %[r], %[w12] row_ror:12 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %[a1], %[r], %[w13] row_ror:13 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %[a2], %[r], %[w14] row_ror:14 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %[a3], %[r], %[w15] row_ror:15 row_mask:0xf bank_mask:0xf"
+        : [a0] "+v"(acc[0]), [a1] "+v"(acc[1]), [a2] "+v"(acc[2]), [a3] "+v"(acc[3])
+        : [r] "v"(Rd[G]), [w0] "v"(w0.v[0]), [w1] "v"(w0.v[1]), [w2] "v"(w0.v[2]), [w3] "v"(w0.v[3]), [w4] "v"(w1.v[0]),
+          [w5] "v"(w1.v[1]), [w6] "v"(w1.v[2]), [w7] "v"(w1.v[3]), [w8] "v"(w2.v[0]), [w9] "v"(w2.v[1]), [w10] "v"(w2.v[2]),
+          [w11] "v"(w2.v[3]), [w12] "v"(w3.v[0]), [w13] "v"(w3.v[1]), [w14] "v"(w3.v[2]), [w15] "v"(w3.v[3]));
     __builtin_amdgcn_sched_barrier(0);
 }
 // hrow != nullptr: the 64 activations h_in[0..63] also sit in LDS (the stage record the DMA delivered): their four 16-lane
