@@ -406,8 +406,9 @@ __device__ __forceinline__ void rows_replicate(float h, float (&R)[4])
 // ---- one hidden layer as ONE asm statement (fp32, weights in registers) ----------------------------------------------------
 // Written as 64 separate asm statements hipcc's hazard recognizer puts an s_nop between any two of them that touch the same
 // register (it assumes an opaque asm may have the dst_sel forwarding hazard and does not count other asm statements as wait
-// states): one s_nop per four FMAs, ~50 per right-hand side, and a wave issues one instruction per ~7 cycles whatever it is
-//  -- an s_nop costs what an FMA costs.  As one statement the layer is 75 instructions instead of 94:
+// states): one s_nop per four FMAs, ~50 per right-hand side.  As one statement the layer is 75 instructions instead of 94
+// (measured: neutral for the forward, -1 % for forward-with-tape and adjoint -- at two waves per SIMD an s_nop of one wave is
+// an issue slot of the other):
 //     v_mov + s_nop 1 + v_permlane16_swap, 2 v_mov + s_nop 0 + 2 v_permlane32_swap     rows of h replicated (rows_replicate)
 //     v_fma + 3 v_mul                                                                  rotation 0, bias folded in
 //     60 v_fmac_f32_dpp                                                                rotations 1..15
