@@ -215,6 +215,8 @@ template <typename R> __device__ __forceinline__ void tableau_rowsT_store(R *row
 // Lane j owns hidden unit j of every layer.  H < 64 is zero-padded (relu(0) = 0 keeps it exact).
 __device__ __forceinline__ float mlp_hidden(const float (&w)[64], float bias, float h);
 __device__ __forceinline__ double mlp_hidden(const double (&w)[64], double bias, double h);
+__device__ __forceinline__ float mlp_hidden_relu(const float (&w)[64], float bias, float h);
+__device__ __forceinline__ double mlp_hidden_relu(const double (&w)[64], double bias, double h);
 template <typename R, int NL> struct MlpRegs {
     R w1[9];                          // W1[j][0..8]
     R b[NL];                          // b_l[j]
@@ -223,7 +225,14 @@ template <typename R, int NL> struct MlpRegs {
     R b5;                             // lane l: bout[l & 7] (0 for slots 6,7)
     // pre-activation of hidden layer l + 2 (l is a compile-time constant at every call site: unrolled layer loop)
     __device__ __forceinline__ R hidden(int l, R h) const { return mlp_hidden(wh[l], b[l + 1], h); }
+    // fp32: the ReLU is the last instruction of the layer's asm statement (hidden_relu); applied to the asm's result from
+    // outside it costs two instructions -- hipcc canonicalises a value it did not compute itself before a max
+    static constexpr bool kHiddenRelu = sizeof(R) == 4;
+    __device__ __forceinline__ R hidden_relu(int l, R h) const { return mlp_hidden_relu(wh[l], b[l + 1], h); }
 };
+// weight holders whose hidden_relu(l, h) returns the POST-activation of hidden layer l + 2
+template <typename T, typename = void> struct applies_relu { static constexpr bool value = false; };
+template <typename T> struct applies_relu<T, decltype((void)T::kHiddenRelu)> { static constexpr bool value = T::kHiddenRelu; };
 
 __host__ __device__ inline int nn_param_count(int H, int L) { return 9 * H + H + (L - 1) * (H * H + H) + 6 * H + 6; }
 
@@ -351,14 +360,9 @@ __device__ __forceinline__ float rpow(float a, float b) { return powf(a, b); }
 __device__ __forceinline__ double rpow(double a, double b) { return pow(a, b); }
 __device__ __forceinline__ float rlog(float a) { return logf(a); }
 __device__ __forceinline__ double rlog(double a) { return log(a); }
-// a / b.  fp32: v_rcp_f32 + one Newton step (|rel err| ~1e-7, 4 VALU instead of the ~10 of an IEEE
-// division); fp64 (parity runs): exact division.
-__device__ __forceinline__ float rdiv(float a, float b)
-{
-    float r = __builtin_amdgcn_rcpf(b);
-    r = __builtin_fmaf(__builtin_fmaf(-b, r, 1.0f), r, r);
-    return a * r;
-}
+// a / b.  fp32: a * v_rcp_f32(b) (the reciprocal is good to 1 ulp; 2 VALU instead of the ~10 of an IEEE division -- a
+// Newton step on the reciprocal, 2 more, bought nothing the fp32 parity bars can see); fp64 (parity runs): exact division.
+__device__ __forceinline__ float rdiv(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
 __device__ __forceinline__ double rdiv(double a, double b) { return a / b; }
 __device__ __forceinline__ float rabs(float a) { return __builtin_fabsf(a); }
 __device__ __forceinline__ double rabs(double a) { return __builtin_fabs(a); }
@@ -428,30 +432,36 @@ __device__ __forceinline__ void rows_replicate(float h, float (&R)[4])
 #define HODE_MV_WEIGHTS \
     HODE_MV_W(0), HODE_MV_W(1), HODE_MV_W(2), HODE_MV_W(3), HODE_MV_W(4), HODE_MV_W(5), HODE_MV_W(6), HODE_MV_W(7), HODE_MV_W(8), \
     HODE_MV_W(9), HODE_MV_W(10), HODE_MV_W(11), HODE_MV_W(12), HODE_MV_W(13), HODE_MV_W(14), HODE_MV_W(15)
-// bias + sum_k W[j][k] h_k with w[16 q + n] on lane j = W[j][16 q + ((j - n) & 15)]
-__device__ __forceinline__ float mlp_hidden(const float (&w)[kMaxH], float bias, float h)
-{
-    float r0 = h, r1, r2, r3, a0, a1, a2, a3;
-    asm("v_mov_b32 %[r1], %[r0]\n\t"
-        "s_nop 1\n\t"
-        "v_permlane16_swap_b32 %[r0], %[r1]\n\t"          // r0 = [h0 h0 h2 h2]   r1 = [h1 h1 h3 h3]   (16-lane rows of h)
-        "v_mov_b32 %[r2], %[r0]\n\t"
-        "v_mov_b32 %[r3], %[r1]\n\t"
-        "s_nop 0\n\t"
-        "v_permlane32_swap_b32 %[r0], %[r2]\n\t"          // r0 = h0 x 4, r2 = h2 x 4
-        "v_permlane32_swap_b32 %[r1], %[r3]\n\t"          // r1 = h1 x 4, r3 = h3 x 4
-        "v_fma_f32 %[a0], %[r0], %[w0_0], %[bias]\n\t"
-        "v_mul_f32 %[a1], %[r1], %[w1_0]\n\t"
-        "v_mul_f32 %[a2], %[r2], %[w2_0]\n\t"
-        "v_mul_f32 %[a3], %[r3], %[w3_0]\n\t"
-        HODE_MV_ROWS_1_15
-        "v_add_f32 %[a0], %[a0], %[a1]\n\t"
-        "v_add_f32 %[a2], %[a2], %[a3]\n\t"
-        "v_add_f32 %[a0], %[a0], %[a2]"
-        : [r0] "+v"(r0), [r1] "=&v"(r1), [r2] "=&v"(r2), [r3] "=&v"(r3), [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2), [a3] "=&v"(a3)
-        : [bias] "v"(bias), HODE_MV_WEIGHTS);
+// bias + sum_k W[j][k] h_k with w[16 q + n] on lane j = W[j][16 q + ((j - n) & 15)]; TAIL = "" or the ReLU
+#define HODE_MV_LAYER(TAIL)                                                                                                   \
+    float r0 = h, r1, r2, r3, a0, a1, a2, a3;                                                                                 \
+    asm("v_mov_b32 %[r1], %[r0]\n\t"                                                                                          \
+        "s_nop 1\n\t"                                                                                                         \
+        "v_permlane16_swap_b32 %[r0], %[r1]\n\t" /* r0 = [h0 h0 h2 h2]   r1 = [h1 h1 h3 h3]   (16-lane rows of h) */          \
+        "v_mov_b32 %[r2], %[r0]\n\t"                                                                                          \
+        "v_mov_b32 %[r3], %[r1]\n\t"                                                                                          \
+        "s_nop 0\n\t"                                                                                                         \
+        "v_permlane32_swap_b32 %[r0], %[r2]\n\t" /* r0 = h0 x 4, r2 = h2 x 4 */                                               \
+        "v_permlane32_swap_b32 %[r1], %[r3]\n\t" /* r1 = h1 x 4, r3 = h3 x 4 */                                               \
+        "v_fma_f32 %[a0], %[r0], %[w0_0], %[bias]\n\t"                                                                        \
+        "v_mul_f32 %[a1], %[r1], %[w1_0]\n\t"                                                                                 \
+        "v_mul_f32 %[a2], %[r2], %[w2_0]\n\t"                                                                                 \
+        "v_mul_f32 %[a3], %[r3], %[w3_0]\n\t"                                                                                 \
+        HODE_MV_ROWS_1_15                                                                                                     \
+        "v_add_f32 %[a0], %[a0], %[a1]\n\t"                                                                                   \
+        "v_add_f32 %[a2], %[a2], %[a3]\n\t"                                                                                   \
+        "v_add_f32 %[a0], %[a0], %[a2]" TAIL                                                                                  \
+        : [r0] "+v"(r0), [r1] "=&v"(r1), [r2] "=&v"(r2), [r3] "=&v"(r3), [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2),      \
+          [a3] "=&v"(a3)                                                                                                      \
+        : [bias] "v"(bias), HODE_MV_WEIGHTS);                                                                                 \
     return a0;
+__device__ __forceinline__ float mlp_hidden(const float (&w)[kMaxH], float bias, float h) { HODE_MV_LAYER("") }
+// max(0, .) of the above: NaN -> 0 like rmax0 (v_max_f32 returns the non-NaN operand)
+__device__ __forceinline__ float mlp_hidden_relu(const float (&w)[kMaxH], float bias, float h)
+{
+    HODE_MV_LAYER("\n\tv_max_f32 %[a0], 0, %[a0]")
 }
+#undef HODE_MV_LAYER
 // acc[q] += sum_n row_ror:n(R[q]) * w[16 q + n], n ascending within each accumulator; R[] must be two wait states old
 __device__ __forceinline__ void rot_matvec64(const float (&w)[kMaxH], const float (&R)[4], float (&acc)[4])
 {
@@ -465,6 +475,11 @@ __device__ __forceinline__ void rot_matvec64(const float (&w)[kMaxH], const floa
 #undef HODE_MV_ROWS_1_15
 #undef HODE_MV_W
 #undef HODE_MV_WEIGHTS
+__device__ __forceinline__ double mlp_hidden_relu(const double (&w)[kMaxH], double bias, double h)
+{
+    const double v = mlp_hidden(w, bias, h);
+    return v > 0.0 ? v : 0.0;
+}
 __device__ __forceinline__ double mlp_hidden(const double (&w)[kMaxH], double bias, double h)
 {
     double acc0 = bias, acc1 = 0.0;
@@ -567,34 +582,77 @@ __device__ __forceinline__ void mlp_outer_acc(double (&gw)[kMaxH], double d, dou
 // Activations kept by the backward pass: h[l] = relu output of hidden layer l+1 on lane j.
 template <typename R, int NL> struct MlpActs { R h[NL]; };
 
+// x_K of the replicated state layout on every lane.  fp32: a DPP row broadcast into a VGPR (lane K of each 16-lane row holds
+// x_K) instead of a v_readlane into an SGPR: the mechanistic terms combine the state with the 17 ODE constants, which live
+// in SGPRs, and a VALU instruction reads at most one SGPR -- every (state, constant) pair cost a v_mov_b32 before.
+template <int K> __device__ __forceinline__ float state_bcast(float Y)
+{
+#ifndef HODE_STATE_SGPR
+    return i2f(__builtin_amdgcn_update_dpp(0, f2i(Y), 0x150 + K, 0xF, 0xF, true));       // row_newbcast:K (every lane written)
+#else
+    return lane_bcast(Y, K);
+#endif
+}
+template <int K> __device__ __forceinline__ double state_bcast(double Y) { return lane_bcast(Y, K); }
+
+// KK with the eight lanes of stage slot s (lanes 8 s .. 8 s + 7) replaced by F.  fp32: the lane mask 0xff << 8 s is scalar
+// arithmetic and feeds v_cndmask_b32 as an SGPR pair -- (lane >> 3) == s costs a shift and a compare on the vector ALU in
+// every stage.  s must be wave-uniform.
+__device__ __forceinline__ float stage_put(float KK, float F, int s)
+{
+    const unsigned long long m = 0xffull << (8 * s);
+    float out;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(out) : "v"(KK), "v"(F), "s"(m));
+    return out;
+}
+__device__ __forceinline__ double stage_put(double KK, double F, int s) { return ((int)(threadIdx.x & 63) >> 3) == s ? F : KK; }
+
+// sel ? term : other, with `term` (a wave-uniform value every lane can compute) evaluated on ALL lanes first.  Left alone,
+// hipcc sinks the arithmetic of each term of a select chain into an exec-masked region of the lanes that keep it: the same
+// VALU instructions plus a v_cmp / s_and_saveexec / s_cbranch_execz round trip per term (measured: 4 % of the forward solve).
+template <typename R> __device__ __forceinline__ R keep_term(bool sel, R term, R other)
+{
+    asm volatile("" : "+v"(term));
+    return sel ? term : other;
+}
+
 // ------------------------------------------------------------------------------------------
 // Mechanistic part (models/ode_core.py:124-153), evaluated redundantly on every lane from the broadcast state; the lane
 // keeps the component of its slot c8 = lane & 7 (GE, slot 4, has no dynamics; slots 6, 7 are padding).
 template <typename R>
 __device__ __forceinline__ R mech_eval(const OdeP<R> &o, R G, R I, R Glu, R GLP1, R FFA, R meal, R gde, int c8)
 {
-    const R Pi = R(1) + o.rho * GLP1;
-    const R dI = Pi * o.a_GI * (G - o.G_b) - o.k_I * (I - o.I_b);
-    const R dGlu = -(o.E_max * rdiv(GLP1, o.EC_50 + GLP1)) * (Glu - o.Glu_b);
-    const R dGLP1 = o.V_max * rdiv(G, o.K_m + G) - o.k_L * GLP1;
-    const R k_GE = o.k_GE0 * (R(1) - gde);
-    const R dFFA = -o.p_7 * FFA - o.p_8 * I * FFA + o.p_9 * G * FFA;
-    const R dG = meal - R(0.01) * (I - o.I_b) + R(0.005) * (Glu - o.Glu_b) - k_GE * G;
-    return (c8 == 0) ? dG : (c8 == 1) ? dI : (c8 == 2) ? dGlu : (c8 == 3) ? dGLP1 : (c8 == 5) ? dFFA : R(0);
+    // Every product / sum is written out (fused where one rounding is saved) and contraction is off: the bits do not depend
+    // on which kernel this is inlined into (the forward variants are compared bit for bit, tests/test_hip_parity.py).
+#pragma clang fp contract(off)
+    const R u = G - o.G_b, v = I - o.I_b, w = Glu - o.Glu_b;
+    const R Pi = rfma(o.rho, GLP1, R(1));
+    R dI = rfma(Pi * o.a_GI, u, -(o.k_I * v));                                     // ode_core.py:124-125
+    R dGlu = -(o.E_max * rdiv(GLP1, o.EC_50 + GLP1)) * w;                          // :129-130
+    R dGLP1 = rfma(o.V_max, rdiv(G, o.K_m + G), -(o.k_L * GLP1));                  // :134-135
+    const R k_GE = o.k_GE0 * (R(1) - gde);                                         // :139-140
+    R dFFA = rfma(o.p_9 * G, FFA, -rfma(o.p_8 * I, FFA, o.p_7 * FFA));             // :144
+    R dG = rfma(-k_GE, G, rfma(R(0.005), w, rfma(R(-0.01), v, meal)));             // :148-150
+    R r = keep_term(c8 == 0, dG, R(0));
+    r = keep_term(c8 == 1, dI, r);
+    r = keep_term(c8 == 2, dGlu, r);
+    r = keep_term(c8 == 3, dGLP1, r);
+    r = keep_term(c8 == 5, dFFA, r);
+    return r;
 }
 
 // ------------------------------------------------------------------------------------------
 // RHS  f(t, x, u) = ODECore + NNResidual  (models/hybrid_ode_nn.py:108-134)
 //   Y   lane-distributed state: lane l holds x_{l&7} (replicated over the eight 8-lane groups;
-//       only lanes 0..5 are read)
+//       fp32 reads lane k of EVERY 16-lane row for x_k, fp64 lane k of the wave)
 //   returns the derivative in the same replicated layout (component slots 6,7 hold 0)
 //   W   weights holder: MlpRegs (everything in VGPRs) or MlpLds (hidden matrices in a workgroup-shared LDS image)
 template <typename R, int NL, bool KEEP, typename WT>
 __device__ __forceinline__ R rhs_eval(const WT &W, const OdeP<R> &o, R t, R Y, R meal, R tvns,
                                       R gde /* Hill term, 0 without GD */, int lane, MlpActs<R, NL> *acts)
 {
-    const R G = lane_bcast(Y, 0), I = lane_bcast(Y, 1), Glu = lane_bcast(Y, 2), GLP1 = lane_bcast(Y, 3),
-            GE = lane_bcast(Y, 4), FFA = lane_bcast(Y, 5);
+    const R G = state_bcast<0>(Y), I = state_bcast<1>(Y), Glu = state_bcast<2>(Y), GLP1 = state_bcast<3>(Y),
+            GE = state_bcast<4>(Y), FFA = state_bcast<5>(Y);
     const int c8 = lane & 7;
     const R mech = mech_eval(o, G, I, Glu, GLP1, FFA, meal, gde, c8);
     // ---- MLP (models/nn_residual.py:138-147): input row [t, G, I, Glu, GLP1, GE, FFA, glp1:=GLP1, tvns]
@@ -612,12 +670,26 @@ __device__ __forceinline__ R rhs_eval(const WT &W, const OdeP<R> &o, R t, R Y, R
     if constexpr (KEEP) acts->h[0] = h;
 #pragma unroll
     for (int l = 0; l < NL - 1; ++l) {
-        h = rmax0(W.hidden(l, h));
+        if constexpr (applies_relu<WT>::value) h = W.hidden_relu(l, h);
+        else h = rmax0(W.hidden(l, h));
         if constexpr (KEEP) acts->h[l + 1] = h;
     }
     R p[6];
+    if constexpr (sizeof(R) == 4) {
+        // three v_pk_mul_f32 instead of six v_mul_f32 (same products)
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        const f2 hh = {h, h};
 #pragma unroll
-    for (int q = 0; q < 6; ++q) p[q] = W.w5[q] * h;
+        for (int q = 0; q < 6; q += 2) {
+            const f2 w = {W.w5[q], W.w5[q + 1]};
+            const f2 pr = w * hh;
+            p[q] = pr.x;
+            p[q + 1] = pr.y;
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) p[q] = W.w5[q] * h;
+    }
     const R nn = wave_reduce6_to_lanes(p, lane);
     return (c8 < 6) ? (mech + nn + W.b5) : R(0);
 }
@@ -935,6 +1007,8 @@ __device__ __forceinline__ R mech_vjp(const OdeP<R> &o, R G, R I, R Glu, R GLP1,
     const R oGLP = o.rho * o.a_GI * (G - o.G_b) * lI - o.E_max * o.EC_50 * r1 * r1 * (Glu - o.Glu_b) * lGlu - o.k_L * lGLP;
     const R oF = (-o.p_7 - o.p_8 * I + o.p_9 * G) * lF;
     const int c8 = lane & 7;
+    // (a keep_term chain as in mech_eval was tried here: the adjoint kernel, at its register limit, answers with 92 B of
+    //  scratch instead of 36)
     const R mech = (c8 == 0) ? oG : (c8 == 1) ? oI : (c8 == 2) ? oGlu : (c8 == 3) ? oGLP : (c8 == 5) ? oF : R(0);
     if constexpr (GODE) {
         R c[17];

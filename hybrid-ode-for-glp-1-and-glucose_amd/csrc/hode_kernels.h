@@ -41,6 +41,7 @@ template <typename R> struct RhsArgs {
 template <typename R> int launch_solve_fwd(hipStream_t s, const SolveArgs<R> &a, int L, int method);
 int launch_solve_fwd_wg(hipStream_t s, const SolveArgs<float> &a, int L, int method);   // hode_solve_fwd_wg.hip (fp32, L = 2..4)
 int launch_solve_fwd_quad(hipStream_t s, const SolveArgs<float> &a, int L, int method); // hode_solve_fwd_quad.hip (fp32, L = 2..4)
+int launch_solve_fwd_rows(hipStream_t s, const SolveArgs<float> &a, int L, int method); // hode_solve_fwd_rows.hip (fp32, L = 2..4)
 template <typename R> int launch_solve_bwd(hipStream_t s, const AdjArgs<R> &a, int L, int method);
 template <typename R> int launch_rhs_fwd(hipStream_t s, const RhsArgs<R> &a, int L);
 template <typename R> int launch_rhs_bwd(hipStream_t s, const RhsArgs<R> &a, int L);

@@ -21,7 +21,7 @@ __global__ __launch_bounds__(256) void rhs_fwd_kernel(const RhsArgs<R> a)
     ode_load(o, a.ode_p);
     const int stride = gridDim.x * 4;
     for (int s = blockIdx.x * 4 + wave; s < a.B; s += stride) {
-        const R Y = (lane < 6) ? a.x[(size_t)s * 6 + lane] : R(0);
+        const R Y = ((lane & 7) < 6) ? a.x[(size_t)s * 6 + (lane & 7)] : R(0);     // replicated layout (rhs_eval)
         const R t = a.t ? a.t[s] : R(0);
         const R meal = a.meal ? a.meal[s] : R(0);
         const R tvns = a.tvns ? a.tvns[s] : R(0);

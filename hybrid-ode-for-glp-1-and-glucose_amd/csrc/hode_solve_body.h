@@ -145,7 +145,7 @@ __device__ __forceinline__ void solve_one(const SolveArgs<R> &a, const int b, co
             for (int s = 0; s < 4; ++s) {
                 const R Ys = rfma(hh, group_sum8(rows[s * kWave + lane] * KK), Y);
                 const R F = f_at(rfma((R)tab.c[s], hh, t0), Ys, ns * 6 + s);
-                KK = (grp == s) ? F : KK;
+                KK = stage_put(KK, F, s);
             }
             tape_put(t0, hh, true);
             Y = rfma(hh, group_sum8(rows[7 * kWave + lane] * KK), Y);
@@ -195,7 +195,7 @@ __device__ __forceinline__ void solve_one(const SolveArgs<R> &a, const int b, co
                         cs = cvec[(s + 1) & 7];
                         // stage s of this step; the FSAL stage (s == 6) is stage 0 of the NEXT step
                         F = f_at(ts, Ys, (s < 6) ? ns * 6 + s : (ns + 1) * 6);
-                        KK = (grp == s) ? F : KK;
+                        KK = stage_put(KK, F, s);
                     }
                     const R Yn = Ys;                      // 5th-order solution
                     nf += 6;

@@ -400,7 +400,7 @@ __global__ __launch_bounds__(256, 1) void rhs_bwd_kernel(const RhsArgs<R> a)
         for (int k = 0; k < kMaxH; ++k) gwh[l][k] = R(0);
     R go = R(0);
     for (int s = blockIdx.x * 4 + wave; s < a.B; s += gridDim.x * 4) {
-        const R Y = (lane < 6) ? a.x[(size_t)s * 6 + lane] : R(0);
+        const R Y = ((lane & 7) < 6) ? a.x[(size_t)s * 6 + (lane & 7)] : R(0);     // replicated layout (rhs_eval)
         const R kb = (lane < 6) ? a.gout[(size_t)s * 6 + lane] : R(0);
         const R t = a.t ? a.t[s] : R(0);
         const R meal = a.meal ? a.meal[s] : R(0);

@@ -55,10 +55,15 @@ static int launch_nl(hipStream_t s, const SolveArgs<R> &a, int method)
 }
 
 // HODE_FWD=wg: the LDS-image workgroup kernel (hode_solve_fwd_wg.hip); HODE_FWD=quad: four trajectories per four waves with
-// column-split weights (hode_solve_fwd_quad.hip); HODE_FWD=regs: this file's kernel
+// column-split weights (hode_solve_fwd_quad.hip); HODE_FWD=rows: four trajectories per four waves, weights split by output
+// rows over the waves and by input blocks over the 16-lane rows (hode_solve_fwd_rows.hip); HODE_FWD=regs: this file's kernel
 static char fwd_mode()
 {
-    static const char v = [] { const char *e = getenv("HODE_FWD"); return e ? e[0] : '\0'; }();
+    static const char v = [] {
+        const char *e = getenv("HODE_FWD");
+        if (e == nullptr) return '\0';
+        return (e[0] == 'r' && e[1] == 'o') ? 'R' : e[0];
+    }();
     return v;
 }
 static bool fwd_use_wg() { return fwd_mode() == 'w'; }
@@ -68,6 +73,7 @@ template <typename R> int launch_solve_fwd(hipStream_t s, const SolveArgs<R> &a,
     if constexpr (sizeof(R) == 4) {
         if (L >= 2 && L <= 4 && fwd_use_wg()) return launch_solve_fwd_wg(s, a, L, method);
         if (L >= 2 && L <= 4 && fwd_mode() == 'q') return launch_solve_fwd_quad(s, a, L, method);
+        if (L >= 2 && L <= 4 && fwd_mode() == 'R') return launch_solve_fwd_rows(s, a, L, method);
     }
     switch (L) {
     case 1: return launch_nl<R, 1>(s, a, method);

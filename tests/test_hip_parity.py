@@ -603,7 +603,9 @@ gx0, gnn, _ = hode.solve_bwd(b, torch.ones_like(b.y))
 np.savez({out!r}, y=a.y.cpu().numpy(), yt=b.y.cpu().numpy(), nfev=a.nfev.cpu().numpy(), gnn=gnn.cpu().numpy())
 """
     ys = {}
-    for mode in ("regs", "wg", "quad"):          # quad: four trajectories per four waves, column-split weights (hode_solve_fwd_quad.hip)
+    # quad: four trajectories per four waves, column-split weights (hode_solve_fwd_quad.hip); rows: split by output rows over
+    # the waves and by input blocks over the 16-lane rows (hode_solve_fwd_rows.hip)
+    for mode in ("regs", "wg", "quad", "rows"):
         env = dict(os.environ, HODE_FWD=mode)
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
@@ -611,7 +613,9 @@ np.savez({out!r}, y=a.y.cpu().numpy(), yt=b.y.cpu().numpy(), nfev=a.nfev.cpu().n
     for k in ("y", "yt", "nfev"):
         assert np.array_equal(ys["regs"][k], ys["wg"][k]), k
         assert np.array_equal(ys["regs"][k], ys["quad"][k]), k
+        assert np.array_equal(ys["regs"][k], ys["rows"][k]), k
     assert relnorm(ys["quad"]["gnn"], ys["regs"]["gnn"]) < 1e-5
+    assert relnorm(ys["rows"]["gnn"], ys["regs"]["gnn"]) < 1e-5
     assert np.array_equal(ys["regs"]["y"], ys["regs"]["yt"])
     # the adjoint consumes the stage tape either kernel wrote: same tape, same gradient up to the atomics' summation order
     assert relnorm(ys["wg"]["gnn"], ys["regs"]["gnn"]) < 1e-5

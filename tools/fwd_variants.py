@@ -2,13 +2,14 @@
     (default)                          register-resident kernel (hode_solve_fwd.hip)
     HODE_FWD=wg HODE_FWD_CFG=<NREG><WPB/4>   workgroup kernel (hode_solve_fwd_wg.hip): 4, 22, default (14)
     HODE_FWD=quad                      four trajectories per four waves, column-split weights (hode_solve_fwd_quad.hip)
+    HODE_FWD=rows                      four trajectories per four waves, weights split by output rows / input blocks (hode_solve_fwd_rows.hip)
 Usage: python tools/fwd_variants.py [B ...]   -> one line per batch size; the first run writes /tmp/fwd_ref_<B>.pt, later runs compare bitwise."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "hybrid-ode-for-glp-1-and-glucose_amd")); sys.path.insert(0, ROOT)
 import torch, hode, bench
 _m = os.environ.get("HODE_FWD", "")
-tag = "wg cfg " + os.environ.get("HODE_FWD_CFG", "default") if _m.startswith("w") else ("quad" if _m.startswith("q") else "regs")
+tag = "wg cfg " + os.environ.get("HODE_FWD_CFG", "default") if _m.startswith("w") else ("quad" if _m.startswith("q") else ("rows" if _m.startswith("ro") else "regs"))
 dev = torch.device("cuda")
 for B in [int(v) for v in sys.argv[1:]] or [4096]:
     x0, t, meal, tv = (v.to(dev) for v in bench.synth_cohort(B, 1000))
