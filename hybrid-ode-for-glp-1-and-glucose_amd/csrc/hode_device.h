@@ -580,7 +580,16 @@ __device__ __forceinline__ void mlp_outer_acc(double (&gw)[kMaxH], double d, dou
 }
 
 // Activations kept by the backward pass: h[l] = relu output of hidden layer l+1 on lane j.
-template <typename R, int NL> struct MlpActs { R h[NL]; };
+template <typename R, int NL> struct MlpActs {
+    R h[NL];
+    __device__ __forceinline__ void put(int l, R v) { h[l] = v; }
+};
+// ... or written straight to the stage record (row l of 64 reals) the moment a layer is done: the forward solve with a tape
+// has no register to hold four rows until the end of the evaluation
+template <typename R> struct ActsToRecord {
+    R *__restrict__ dst;                  // record + lane
+    __device__ __forceinline__ void put(int l, R v) { dst[l * kWave] = v; }
+};
 
 // x_K of the replicated state layout on every lane.  fp32: a DPP row broadcast into a VGPR (lane K of each 16-lane row holds
 // x_K) instead of a v_readlane into an SGPR: the mechanistic terms combine the state with the 17 ODE constants, which live
@@ -647,9 +656,9 @@ __device__ __forceinline__ R mech_eval(const OdeP<R> &o, R G, R I, R Glu, R GLP1
 //       fp32 reads lane k of EVERY 16-lane row for x_k, fp64 lane k of the wave)
 //   returns the derivative in the same replicated layout (component slots 6,7 hold 0)
 //   W   weights holder: MlpRegs (everything in VGPRs) or MlpLds (hidden matrices in a workgroup-shared LDS image)
-template <typename R, int NL, bool KEEP, typename WT>
+template <typename R, int NL, bool KEEP, typename WT, typename ACTS = MlpActs<R, NL>>
 __device__ __forceinline__ R rhs_eval(const WT &W, const OdeP<R> &o, R t, R Y, R meal, R tvns,
-                                      R gde /* Hill term, 0 without GD */, int lane, MlpActs<R, NL> *acts)
+                                      R gde /* Hill term, 0 without GD */, int lane, ACTS *acts)
 {
     const R G = state_bcast<0>(Y), I = state_bcast<1>(Y), Glu = state_bcast<2>(Y), GLP1 = state_bcast<3>(Y),
             GE = state_bcast<4>(Y), FFA = state_bcast<5>(Y);
@@ -667,12 +676,12 @@ __device__ __forceinline__ R rhs_eval(const WT &W, const OdeP<R> &o, R t, R Y, R
     h = rfma(W.w1[7], GLP1, h);
     h = rfma(W.w1[8], tvns, h);
     h = rmax0(h);
-    if constexpr (KEEP) acts->h[0] = h;
+    if constexpr (KEEP) acts->put(0, h);
 #pragma unroll
     for (int l = 0; l < NL - 1; ++l) {
         if constexpr (applies_relu<WT>::value) h = W.hidden_relu(l, h);
         else h = rmax0(W.hidden(l, h));
-        if constexpr (KEEP) acts->h[l + 1] = h;
+        if constexpr (KEEP) acts->put(l + 1, h);
     }
     R p[6];
     if constexpr (sizeof(R) == 4) {

@@ -26,7 +26,7 @@ __global__ __launch_bounds__(256) void rhs_fwd_kernel(const RhsArgs<R> a)
         const R meal = a.meal ? a.meal[s] : R(0);
         const R tvns = a.tvns ? a.tvns[s] : R(0);
         const R gde = a.gd ? gd_effect(o, a.gd[s]) : R(0);
-        const R F = rhs_eval<R, NL, false>(W, o, t, Y, meal, tvns, gde, lane, nullptr);
+        const R F = rhs_eval<R, NL, false>(W, o, t, Y, meal, tvns, gde, lane, (MlpActs<R, NL> *)nullptr);
         if (lane < 6) a.out[(size_t)s * 6 + lane] = F;
     }
 }

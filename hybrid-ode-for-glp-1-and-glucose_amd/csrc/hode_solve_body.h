@@ -37,15 +37,12 @@ template <typename R, int NL, typename WT> struct RhsRegs {
     __device__ __forceinline__ R operator()(R ts, R Ys, R meal, R tvns, R gde, R *__restrict__ rec) const
     {
         if (rec != nullptr) {
-            MlpActs<R, NL> ac;
+            ActsToRecord<R> ac{rec + lane};
             const R F = rhs_eval<R, NL, true>(W, o, ts, Ys, meal, tvns, gde, lane, &ac);
-            R *dst = rec + lane;
-#pragma unroll
-            for (int l = 0; l < NL; ++l) dst[l * kWave] = ac.h[l];
-            if (lane < 8) dst[NL * kWave] = Ys;
+            if (lane < 8) ac.dst[NL * kWave] = Ys;
             return F;
         }
-        return rhs_eval<R, NL, false>(W, o, ts, Ys, meal, tvns, gde, lane, nullptr);
+        return rhs_eval<R, NL, false>(W, o, ts, Ys, meal, tvns, gde, lane, (MlpActs<R, NL> *)nullptr);
     }
 };
 
@@ -75,22 +72,29 @@ __device__ __forceinline__ void solve_one(const SolveArgs<R> &a, const int b, co
     // stores (a 24-byte store per grid point costs a partial cache line each: measured 1.9x write traffic)
     int ypos = 0;                             // staged reals
     size_t ybase = 0;                         // reals already written
+    // (the lane index is laundered in both: hipcc otherwise hoists the per-lane addresses ybuf + lane and yb + lane out of
+    //  the integration -- three VGPRs for the whole kernel, which the taping instantiation spills and reloads from scratch,
+    //  with a full wait, at every grid point; recomputing them is two instructions per grid point)
     auto y_put = [&](R v) {
-        if (lane < 6) ybuf[ypos + lane] = v;
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        if (ln < 6) ybuf[ypos + ln] = v;
         ypos += 6;
         if (ypos >= kWave) {
             __builtin_amdgcn_wave_barrier();
-            yb[ybase + lane] = ybuf[lane];
-            const R carry = (lane < 8) ? ybuf[kWave + lane] : R(0);
+            yb[ybase + ln] = ybuf[ln];
+            const R carry = (ln < 8) ? ybuf[kWave + ln] : R(0);
             __builtin_amdgcn_wave_barrier();
-            if (lane < 8) ybuf[lane] = carry;
+            if (ln < 8) ybuf[ln] = carry;
             ybase += kWave;
             ypos -= kWave;
         }
     };
     auto y_flush = [&]() {
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
         __builtin_amdgcn_wave_barrier();
-        if (lane < ypos) yb[ybase + lane] = ybuf[lane];
+        if (ln < ypos) yb[ybase + ln] = ybuf[ln];
         ybase += ypos;
         ypos = 0;
     };
@@ -131,7 +135,11 @@ __device__ __forceinline__ void solve_one(const SolveArgs<R> &a, const int b, co
             if constexpr (TAPE) {
                 // entry = {t, h, y0..y5}: lanes 0..5 store the state, lanes 6,7 store t and h
                 const R e = (lane < 6) ? Y : (lane == 6) ? tc : h;
-                if (lane < 8) tape[(size_t)ns * 8 + ((lane < 6) ? lane + 2 : lane - 6)] = e;
+                // (the lane's slot is laundered: hipcc otherwise keeps the per-lane pointer tape + slot live across the whole
+                //  integration -- two VGPRs the kernel does not have: it was spilled and reloaded from scratch every step)
+                int slot_l = (lane < 6) ? lane + 2 : lane - 6;
+                asm volatile("" : "+v"(slot_l));
+                if (lane < 8) tape[(size_t)ns * 8 + slot_l] = e;
                 if (lane == 0) tseg[ns] = k | (closes ? kSegClosed : 0);
             }
         };

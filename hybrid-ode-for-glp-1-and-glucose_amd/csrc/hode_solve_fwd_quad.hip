@@ -127,15 +127,12 @@ template <int NL> struct RhsQuad {
     {
         (void)W.round_begin(true);
         if (rec != nullptr) {
-            MlpActs<float, NL> ac;
+            ActsToRecord<float> ac{rec + lane};
             const float F = rhs_eval<float, NL, true>(W, o, ts, Ys, meal, tvns, gde, lane, &ac);
-            float *dst = rec + lane;
-#pragma unroll
-            for (int l = 0; l < NL; ++l) dst[l * kWave] = ac.h[l];
-            if (lane < 8) dst[NL * kWave] = Ys;
+            if (lane < 8) ac.dst[NL * kWave] = Ys;
             return F;
         }
-        return rhs_eval<float, NL, false>(W, o, ts, Ys, meal, tvns, gde, lane, nullptr);
+        return rhs_eval<float, NL, false>(W, o, ts, Ys, meal, tvns, gde, lane, (MlpActs<float, NL> *)nullptr);
     }
 };
 
