@@ -847,6 +847,29 @@ __device__ __forceinline__ void layer_bwd_group(float (&gw)[kMaxH], const Vec4<f
     // rows 4G..4G+3 of the image: r = 16 G + 4 i + c  ->  q = G, n = 4 i + c.  ONE asm statement: between separate
     // statements that share an accumulator hipcc inserts an s_nop (see mlp_hidden above)
     static_assert(G >= 0 && G < 4, "four groups of sixteen rotations");
+    if constexpr (G == 0) {
+        // the first group starts the four sums with products: no zero-initialised accumulators (four v_mov_b32 per layer)
+        asm("v_mul_f32 %[a0], %[r], %[w0]\n\t"
+            "v_mul_f32_dpp %[a1], %[r], %[w1] row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+            "v_mul_f32_dpp %[a2], %[r], %[w2] row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+            "v_mul_f32_dpp %[a3], %[r], %[w3] row_ror:3 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %[a0], %[r], %[w4] row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %[a1], %[r], %[w5] row_ror:5 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %[a2], %[r], %[w6] row_ror:6 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %[a3], %[r], %[w7] row_ror:7 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %[a0], %[r], %[w8] row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %[a1], %[r], %[w9] row_ror:9 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %[a2], %[r], %[w10] row_ror:10 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %[a3], %[r], %[w11] row_ror:11 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %[a0], %[r], %[w12] row_ror:12 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %[a1], %[r], %[w13] row_ror:13 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %[a2], %[r], %[w14] row_ror:14 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %[a3], %[r], %[w15] row_ror:15 row_mask:0xf bank_mask:0xf"
+            : [a0] "=&v"(acc[0]), [a1] "=&v"(acc[1]), [a2] "=&v"(acc[2]), [a3] "=&v"(acc[3])
+        : [r] "v"(Rd[G]), [w0] "v"(w0.v[0]), [w1] "v"(w0.v[1]), [w2] "v"(w0.v[2]), [w3] "v"(w0.v[3]), [w4] "v"(w1.v[0]),
+          [w5] "v"(w1.v[1]), [w6] "v"(w1.v[2]), [w7] "v"(w1.v[3]), [w8] "v"(w2.v[0]), [w9] "v"(w2.v[1]), [w10] "v"(w2.v[2]),
+          [w11] "v"(w2.v[3]), [w12] "v"(w3.v[0]), [w13] "v"(w3.v[1]), [w14] "v"(w3.v[2]), [w15] "v"(w3.v[3]));
+    } else {
     asm("v_fmac_f32 %[a0], %[r], %[w0]\n\t"
         "v_fmac_f32_dpp %[a1], %[r], %[w1] row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
         "v_fmac_f32_dpp %[a2], %[r], %[w2] row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
@@ -867,6 +890,7 @@ __device__ __forceinline__ void layer_bwd_group(float (&gw)[kMaxH], const Vec4<f
         : [r] "v"(Rd[G]), [w0] "v"(w0.v[0]), [w1] "v"(w0.v[1]), [w2] "v"(w0.v[2]), [w3] "v"(w0.v[3]), [w4] "v"(w1.v[0]),
           [w5] "v"(w1.v[1]), [w6] "v"(w1.v[2]), [w7] "v"(w1.v[3]), [w8] "v"(w2.v[0]), [w9] "v"(w2.v[1]), [w10] "v"(w2.v[2]),
           [w11] "v"(w2.v[3]), [w12] "v"(w3.v[0]), [w13] "v"(w3.v[1]), [w14] "v"(w3.v[2]), [w15] "v"(w3.v[3]));
+    }
     __builtin_amdgcn_sched_barrier(0);
 }
 // hrow != nullptr: the 64 activations h_in[0..63] also sit in LDS (the stage record the DMA delivered): their four 16-lane
@@ -887,7 +911,7 @@ __device__ __forceinline__ float layer_bwd(float (&gw)[kMaxH], const WtLds<float
         rows_replicate(hin, Rh);
     }
     rows_replicate(d, Rd);
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    float acc[4];                                   // started by group 0
     __builtin_amdgcn_sched_barrier(0);
     layer_bwd_group<0>(gw, wt4, lane, d, Rh, Rd, acc);
     layer_bwd_group<1>(gw, wt4, lane, d, Rh, Rd, acc);
@@ -1016,8 +1040,9 @@ __device__ __forceinline__ R mech_vjp(const OdeP<R> &o, R G, R I, R Glu, R GLP1,
     const R oGLP = o.rho * o.a_GI * (G - o.G_b) * lI - o.E_max * o.EC_50 * r1 * r1 * (Glu - o.Glu_b) * lGlu - o.k_L * lGLP;
     const R oF = (-o.p_7 - o.p_8 * I + o.p_9 * G) * lF;
     const int c8 = lane & 7;
-    // (a keep_term chain as in mech_eval was tried here: the adjoint kernel, at its register limit, answers with 92 B of
-    //  scratch instead of 36)
+    // (select chains that keep hipcc from sinking the terms into exec-masked regions -- keep_term as in mech_eval, or
+    //  v_cndmask_b32 with literal lane masks -- were tried here: the adjoint kernel, at its register limit, answers with
+    //  60-90 B of scratch instead of 28-36 and reloads inside the stage loop)
     const R mech = (c8 == 0) ? oG : (c8 == 1) ? oI : (c8 == 2) ? oGlu : (c8 == 3) ? oGLP : (c8 == 5) ? oF : R(0);
     if constexpr (GODE) {
         R c[17];
