@@ -46,6 +46,23 @@ template <typename R, int NL, typename WT> struct RhsRegs {
     }
 };
 
+// en^(-1/5) for the step-size factor (scipy/integrate/_ivp/rk.py:150-176).  fp32: v_log_f32 / v_exp_f32 as they are (the
+// library forms wrap each in a denormal-range rescaling, ~8 instructions; a denormal en gives the factor its cap, 10).
+template <typename R> __device__ __forceinline__ float pow_m02(float en)
+{
+    if constexpr (sizeof(R) == 4) return __builtin_amdgcn_exp2f(-0.2f * __builtin_amdgcn_logf(en));
+    else return __builtin_exp2f(-0.2f * __builtin_log2f(en));
+}
+
+// sqrt(sum / 6): the RMS norm of the step controller (scipy/integrate/_ivp/common.py:63-66).  The fp32 instantiation takes
+// v_sqrt_f32 and a multiplication (1 ulp each) instead of the IEEE square root and division hipcc expands to ~25
+// instructions per step; the fp64 parity instantiation keeps the exact forms.
+template <typename R> __device__ __forceinline__ float rms6(float sum)
+{
+    if constexpr (sizeof(R) == 4) return __builtin_amdgcn_sqrtf(sum * (1.0f / 6.0f));
+    else return sqrtf(sum / 6.0f);
+}
+
 // rows  [8][64] tableau coefficient rows, cvec [8] tableau nodes (LDS, shared by the workgroup)
 // ybuf  [64 + 8] output staging of THIS wave (LDS)
 // rhs   the right-hand side functor of trajectory b's parameter set; o = its 17 mechanistic constants (Hill term)
@@ -209,12 +226,12 @@ __device__ __forceinline__ void solve_one(const SolveArgs<R> &a, const int b, co
                     nf += 6;
                     const R err = h * group_sum8(coef * KK);
                     const R ymax = rabs(Y) > rabs(Yn) ? rabs(Y) : rabs(Yn);
-                    const R qe = (c8 < 6) ? err / (a.atol + ymax * a.rtol) : R(0);
-                    float en = sqrtf((float)first_lane(oct_allsum(qe * qe)) / 6.0f);
+                    const R qe = (c8 < 6) ? rdiv(err, a.atol + ymax * a.rtol) : R(0);
+                    float en = rms6<R>((float)first_lane(oct_allsum(qe * qe)));
                     const float ysum = (float)first_lane(oct_allsum(Yn));
                     if (!(en == en) || !(fabsf(ysum) <= 3.0e38f) || !(fabsf(en) <= 3.0e38f)) en = 1e30f;
                     if (en < 1.0f) {
-                        float fac = (en == 0.0f) ? 10.0f : fminf(10.0f, 0.9f * __builtin_exp2f(-0.2f * __builtin_log2f(en)));
+                        float fac = (en == 0.0f) ? 10.0f : fminf(10.0f, 0.9f * pow_m02<R>(en));
                         if (rejected) fac = fminf(1.0f, fac);
                         tape_put(tc, h, clipped);
                         const R hn = h * (R)fac;
@@ -225,7 +242,7 @@ __device__ __forceinline__ void solve_one(const SolveArgs<R> &a, const int b, co
                         ns++;
                         break;
                     } else {
-                        h_abs = first_lane(h * (R)fmaxf(0.2f, 0.9f * __builtin_exp2f(-0.2f * __builtin_log2f(en))));
+                        h_abs = first_lane(h * (R)fmaxf(0.2f, 0.9f * pow_m02<R>(en)));
                         rejected = true;
                         if (en >= 1e30f && !(h_abs > min_step)) { st = HODE_ST_NONFINITE; break; }
                     }
