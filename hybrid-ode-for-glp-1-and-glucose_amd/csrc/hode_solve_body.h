@@ -215,7 +215,9 @@ __device__ __forceinline__ void solve_one(const SolveArgs<R> &a, const int b, co
 #pragma unroll 1
                     for (int s = 1; s <= 6; ++s) {        // stages 2..6 and the FSAL stage (row 6 = 5th-order weights)
                         Ys = rfma(h, group_sum8(coef * KK), Y);
-                        const R ts = (s >= 5) ? tn : rfma(cs, h, tc);
+                        // both candidates are wave-uniform: select on the scalar unit.  (A v_cndmask_b32 whose VCC mask was
+                        // written by the scalar unit costs 12-19 cycles instead of 3, tools/ubench/vcc_ubench.hip.)
+                        const R ts = (s >= 5) ? tn : first_lane(rfma(cs, h, tc));
                         coef = rows[(s + 1) * kWave + lane];   // s = 6 fetches row 7 = error weights
                         cs = cvec[(s + 1) & 7];
                         // stage s of this step; the FSAL stage (s == 6) is stage 0 of the NEXT step
@@ -227,15 +229,15 @@ __device__ __forceinline__ void solve_one(const SolveArgs<R> &a, const int b, co
                     const R err = h * group_sum8(coef * KK);
                     const R ymax = rabs(Y) > rabs(Yn) ? rabs(Y) : rabs(Yn);
                     const R qe = (c8 < 6) ? rdiv(err, a.atol + ymax * a.rtol) : R(0);
-                    float en = rms6<R>((float)first_lane(oct_allsum(qe * qe)));
+                    float en = first_lane(rms6<R>((float)first_lane(oct_allsum(qe * qe))));   // scalar from here on
                     const float ysum = (float)first_lane(oct_allsum(Yn));
                     if (!(en == en) || !(fabsf(ysum) <= 3.0e38f) || !(fabsf(en) <= 3.0e38f)) en = 1e30f;
                     if (en < 1.0f) {
                         float fac = (en == 0.0f) ? 10.0f : fminf(10.0f, 0.9f * pow_m02<R>(en));
                         if (rejected) fac = fminf(1.0f, fac);
                         tape_put(tc, h, clipped);
-                        const R hn = h * (R)fac;
-                        h_abs = first_lane((clipped && hn < h_abs) ? h_abs : hn);   // a clipped step never shrinks the proposal
+                        const R hn = first_lane(h * (R)fac);
+                        h_abs = (clipped && hn < h_abs) ? h_abs : hn;               // a clipped step never shrinks the proposal
                         Y = Yn;
                         KK = (grp == 0) ? F : KK;         // FSAL: K7 becomes K1
                         tc = tn;
