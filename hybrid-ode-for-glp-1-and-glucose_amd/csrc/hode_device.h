@@ -222,6 +222,7 @@ template <typename R, int NL> struct MlpRegs {
     R b[NL];                          // b_l[j]
     R wh[(NL > 1) ? NL - 1 : 1][kMaxH]; // W_l[j][0..63], l = 2..NL
     R w5[6];                          // Wout[o][j]
+    R w5r[8];                         // fp32: Wout[lane & 7] in rotating order (out_rot_fill); unused in fp64
     R b5;                             // lane l: bout[l & 7] (0 for slots 6,7)
     // pre-activation of hidden layer l + 2 (l is a compile-time constant at every call site: unrolled layer loop)
     __device__ __forceinline__ R hidden(int l, R h) const { return mlp_hidden(wh[l], b[l + 1], h); }
@@ -253,6 +254,25 @@ constexpr int kStageElems = (kMaxH / 2) * kStageStride;      // two passes of 32
 // may be nullptr for fp64): every lane reads its weight row with coalesced 16-byte loads, drops it into LDS
 // and reads it back in the lane-dependent rotated order -- no per-lane gather from global memory (which
 // cost 630 B/lane of scratch spills = 170 MB of extra HBM traffic per launch) and no long-lived temporaries.
+// Output layer in rotating order (fp32): lane (r, i) = lane 16 r + i keeps, for output o = i & 7,
+//     w5r[n] = Wout[o][16 r + ((i - n) & 15)]   n = 0..7        (zero for o >= 6)
+// so that sum_n row_ror:n(h) * w5r[n] -- 8 FMAs on the activation vector in its natural layout -- is one half of the lane's
+// row-r part of output o; lane i + 8 of the same row (same output) holds the other half (its eight sources are the other
+// eight lanes), a row_ror:8 add joins them, and an all-reduce over the four rows (2 swaps + 2 adds) leaves out_o on every lane
+// with i & 7 == o: the replicated layout of the state.  15 vector instructions instead of the 35 of six products +
+// wave_reduce6_to_lanes, for two more weight registers.
+template <typename WT> __device__ __forceinline__ void out_rot_fill(WT &W, const float *__restrict__ pout, int H, int lane)
+{
+    const int i = lane & 15, r = lane >> 4, o = lane & 7;
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+        const int k = 16 * r + ((i - n) & 15);
+        const bool ok = o < 6 && k < H;
+        W.w5r[n] = ok ? pout[(ok ? o : 0) * H + (ok ? k : 0)] : 0.f;
+    }
+}
+template <typename WT> __device__ __forceinline__ void out_rot_fill(WT &, const double *__restrict__, int, int) {}
+
 // first / last layer weights and all biases ("edge" parameters) of one parameter set -> registers of lane j
 template <typename R, int NL, typename WT>
 __device__ __forceinline__ void mlp_load_edges(WT &W, const R *__restrict__ p, int H, int lane)
@@ -272,6 +292,7 @@ __device__ __forceinline__ void mlp_load_edges(WT &W, const R *__restrict__ p, i
     }
 #pragma unroll
     for (int o = 0; o < 6; ++o) W.w5[o] = live * p[o * H + j];
+    out_rot_fill(W, p, H, lane);
     p += 6 * H;
     W.b5 = ((lane & 7) < 6) ? p[((lane & 7) < 6) ? (lane & 7) : 0] : R(0);   // replicated per 8-lane group
 }
@@ -337,6 +358,7 @@ __device__ __forceinline__ void mlp_load(MlpRegs<R, NL> &W, const R *__restrict_
     }
 #pragma unroll
     for (int o = 0; o < 6; ++o) W.w5[o] = live * p[o * H + j];
+    out_rot_fill(W, p, H, lane);
     p += 6 * H;
     W.b5 = ((lane & 7) < 6) ? p[((lane & 7) < 6) ? (lane & 7) : 0] : R(0);   // replicated per 8-lane group
 }
@@ -537,6 +559,7 @@ template <int NL, int NREG> struct MlpLds {
     float w1[9];
     float b[NL];
     float w5[6];
+    float w5r[8];
     float b5;
     float whr[(NREG > 0) ? NREG : 1][kMaxH];      // the first NREG hidden matrices, register-resident
     const float4 *img;                            // all NL-1 matrices (LDS)
@@ -650,6 +673,32 @@ __device__ __forceinline__ R mech_eval(const OdeP<R> &o, R G, R I, R Glu, R GLP1
     return r;
 }
 
+// the output layer of out_rot_fill: 1 v_mul + 7 v_fmac_f32_dpp on h (natural layout; the s_nop gives the DPP read of h its
+// second wait state after the v_max that produced it), the row_ror:8 add of the two half sums, the all-reduce over the rows.
+__device__ __forceinline__ float out_rot(const float (&w)[8], float h)
+{
+    float a, t;
+#define HODE_OR(n) "v_fmac_f32_dpp %[a], %[h], %[w" #n "] row_ror:" #n " row_mask:0xf bank_mask:0xf\n\t"
+    asm("v_mul_f32 %[a], %[h], %[w0]\n\t"
+        "s_nop 0\n\t"
+        HODE_OR(1) HODE_OR(2) HODE_OR(3) HODE_OR(4) HODE_OR(5) HODE_OR(6) HODE_OR(7)
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %[a], %[a], %[a] row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32 %[t], %[a]\n\t"
+        "s_nop 1\n\t"
+        "v_permlane16_swap_b32 %[a], %[t]\n\t"       // a = [r0 r0 r2 r2], t = [r1 r1 r3 r3]
+        "v_add_f32 %[a], %[a], %[t]\n\t"             // [r0+r1 x2, r2+r3 x2]
+        "v_mov_b32 %[t], %[a]\n\t"
+        "s_nop 1\n\t"
+        "v_permlane32_swap_b32 %[a], %[t]\n\t"       // a = [r0+r1 x4], t = [r2+r3 x4]
+        "v_add_f32 %[a], %[a], %[t]"
+        : [a] "=&v"(a), [t] "=&v"(t)
+        : [h] "v"(h), [w0] "v"(w[0]), [w1] "v"(w[1]), [w2] "v"(w[2]), [w3] "v"(w[3]), [w4] "v"(w[4]), [w5] "v"(w[5]), [w6] "v"(w[6]),
+          [w7] "v"(w[7]));
+#undef HODE_OR
+    return a;
+}
+
 // ------------------------------------------------------------------------------------------
 // RHS  f(t, x, u) = ODECore + NNResidual  (models/hybrid_ode_nn.py:108-134)
 //   Y   lane-distributed state: lane l holds x_{l&7} (replicated over the eight 8-lane groups;
@@ -683,23 +732,15 @@ __device__ __forceinline__ R rhs_eval(const WT &W, const OdeP<R> &o, R t, R Y, R
         else h = rmax0(W.hidden(l, h));
         if constexpr (KEEP) acts->put(l + 1, h);
     }
-    R p[6];
+    R nn;
     if constexpr (sizeof(R) == 4) {
-        // three v_pk_mul_f32 instead of six v_mul_f32 (same products)
-        typedef float f2 __attribute__((ext_vector_type(2)));
-        const f2 hh = {h, h};
-#pragma unroll
-        for (int q = 0; q < 6; q += 2) {
-            const f2 w = {W.w5[q], W.w5[q + 1]};
-            const f2 pr = w * hh;
-            p[q] = pr.x;
-            p[q + 1] = pr.y;
-        }
+        nn = out_rot(W.w5r, h);
     } else {
+        R p[6];
 #pragma unroll
         for (int q = 0; q < 6; ++q) p[q] = W.w5[q] * h;
+        nn = wave_reduce6_to_lanes(p, lane);
     }
-    const R nn = wave_reduce6_to_lanes(p, lane);
     return (c8 < 6) ? (mech + nn + W.b5) : R(0);
 }
 

@@ -46,6 +46,7 @@ template <int NL> struct MlpQuad {
     float w1[9];
     float b[NL];
     float w5[6];
+    float w5r[8];
     float b5;
     float wq[(NL > 1) ? NL - 1 : 1][16];      // wq[l][n] on lane j = W_l[j][16 wave + ((j - n) & 15)]
     float *xh;                                 // LDS [4][64]     activation of each trajectory (input of the current layer)

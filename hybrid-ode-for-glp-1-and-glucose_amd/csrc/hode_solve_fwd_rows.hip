@@ -40,6 +40,7 @@ template <int NL> struct MlpRows {
     float w1[9];
     float b[NL];
     float w5[6];
+    float w5r[8];
     float b5;
     float wq[(NL > 1) ? NL - 1 : 1][16];      // wq[l][n] on lane (r, i) = W_l[16 wave + i][16 r + ((i - n) & 15)]
     float bq[(NL > 1) ? NL - 1 : 1];          // b_{l+1}[16 wave + i] on the lanes of row 0, zero elsewhere
