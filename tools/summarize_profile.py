@@ -19,8 +19,11 @@ def short(name):
     return name[:name.index("(")] if "(" in name else name
 
 
-stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
-rows = list(csv.DictReader(open(stats[0])))
+stats = sorted(glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv")), key=os.path.getmtime)
+if len(stats) > 1:
+    sys.exit(f"{src} holds the output of {len(stats)} profiling runs (gpurun merges into gpurun_out/): delete the directory before "
+             "the run, or the stale files -- the counters of different kernel versions would be averaged together")
+rows = list(csv.DictReader(open(stats[-1])))
 with open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w") as f:
     f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --train-steps 2 --no-cpu-baseline\n")
     f.write("kernel,calls,total_ns,avg_ns,pct,min_ns,max_ns\n")
