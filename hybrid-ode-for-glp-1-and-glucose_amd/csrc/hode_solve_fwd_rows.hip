@@ -21,6 +21,12 @@
 // Everything else -- first / last layer, mechanistic terms, Runge-Kutta algebra, step-size control, output staging -- stays
 // private to the wave that owns the trajectory (solve_one, hode_solve_body.h).  128 VGPRs: four waves per SIMD.
 //
+// MEASURED (MI355X, fp32, T = 241, profiles/r02_fwd_variants_final.log): 3.87 ms at 4 096 trajectories against 3.57 for the
+// register kernel, 7.00 against 6.90 at 8 192 -- within 2 % at twice the occupancy.  The SQ counters (tools/pmc_fwd_variant.sh)
+// say why: both kernels issue the same ~4.4 G vector instructions per launch at ~4.3 shader cycles each; the forward solve is
+// bound by its instruction count, not by occupancy, and four barriers per RHS cost what the missing
+// v_permlane swaps save.  Kept opt-in.
+//
 // Lock step.  A layer needs all four waves, so the four trajectories evaluate their right-hand sides in rounds: one round =
 // NL exchanges (h_1 of every trajectory out, then one per hidden matrix).  The "still integrating" flags travel with the
 // first exchange.  A wave whose trajectory has finished (or that has none: ragged last workgroup) keeps serving rounds with
