@@ -53,15 +53,23 @@ FLOP_PER_4GI_RHS = 60 + 3 * 40
 FLOP_PER_4GI_STEP = 6 * FLOP_PER_4GI_RHS + 8 * 2 * (21 + 7) + 40
 
 
-def kernel_source_sha():
-    """sha256 over the kernel sources: profiles/pmc_traffic.json carries the value it was measured at, so a PMC reading
-    taken on other kernels is never reported as this run's traffic."""
+def _strip_c_comments(text):
+    """C / C++ source without comments and with runs of white space collapsed (string literals are kept as they are)."""
+    import re
+    pat = re.compile(r'//[^\n]*|/\*.*?\*/|"(?:\\.|[^"\\])*"|\'(?:\\.|[^\'\\])*\'', re.S)
+    text = pat.sub(lambda m: m.group(0) if m.group(0)[0] in "\"'" else " ", text)
+    return re.sub(r"\s+", " ", text)
+
+
+def kernel_source_sha(root=None):
+    """sha256 over the CODE of the kernel sources (comments and white space do not count): profiles/pmc_traffic.json carries
+    the value it was measured at, so a PMC reading taken on other kernels is never reported as this run's traffic."""
     import glob
     import hashlib
     h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(ROOT, "hybrid-ode-for-glp-1-and-glucose_amd", "csrc", "*.h*"))):
+    for f in sorted(glob.glob(os.path.join(root or ROOT, "hybrid-ode-for-glp-1-and-glucose_amd", "csrc", "*.h*"))):
         h.update(os.path.basename(f).encode())
-        h.update(open(f, "rb").read())
+        h.update(_strip_c_comments(open(f, "r", errors="replace").read()).encode())
     return h.hexdigest()[:16]
 
 
