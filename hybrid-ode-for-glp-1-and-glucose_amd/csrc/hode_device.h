@@ -216,20 +216,30 @@ template <typename R> __device__ __forceinline__ void tableau_rowsT_store(R *row
 __device__ __forceinline__ float mlp_hidden(const float (&w)[64], float bias, float h);
 __device__ __forceinline__ double mlp_hidden(const double (&w)[64], double bias, double h);
 __device__ __forceinline__ float mlp_hidden_relu(const float (&w)[64], float bias, float h);
+template <bool RELU> __device__ __forceinline__ float mlp_hidden_blk(const float (&w)[64], float bias, float h);
+template <bool RELU> __device__ __forceinline__ double mlp_hidden_blk(const double (&)[64], double, double) { return 0.0; }
 __device__ __forceinline__ double mlp_hidden_relu(const double (&w)[64], double bias, double h);
 template <typename R, int NL> struct MlpRegs {
     R w1[9];                          // W1[j][0..8]
     R b[NL];                          // b_l[j]
-    R wh[(NL > 1) ? NL - 1 : 1][kMaxH]; // W_l[j][0..63], l = 2..NL
+    R wh[(NL > 1) ? NL - 1 : 1][kMaxH]; // fp64: W_l[j][0..63], l = 2..NL; fp32: the row-block order of mlp_hidden_blk
     R w5[6];                          // Wout[o][j]
     R w5r[8];                         // fp32: Wout[lane & 7] in rotating order (out_rot_fill); unused in fp64
     R b5;                             // lane l: bout[l & 7] (0 for slots 6,7)
     // pre-activation of hidden layer l + 2 (l is a compile-time constant at every call site: unrolled layer loop)
-    __device__ __forceinline__ R hidden(int l, R h) const { return mlp_hidden(wh[l], b[l + 1], h); }
+    __device__ __forceinline__ R hidden(int l, R h) const
+    {
+        if constexpr (sizeof(R) == 4) return mlp_hidden_blk<false>(wh[l], b[l + 1], h);
+        else return mlp_hidden(wh[l], b[l + 1], h);
+    }
     // fp32: the ReLU is the last instruction of the layer's asm statement (hidden_relu); applied to the asm's result from
     // outside it costs two instructions -- hipcc canonicalises a value it did not compute itself before a max
     static constexpr bool kHiddenRelu = sizeof(R) == 4;
-    __device__ __forceinline__ R hidden_relu(int l, R h) const { return mlp_hidden_relu(wh[l], b[l + 1], h); }
+    __device__ __forceinline__ R hidden_relu(int l, R h) const
+    {
+        if constexpr (sizeof(R) == 4) return mlp_hidden_blk<true>(wh[l], b[l + 1], h);
+        else return mlp_hidden_relu(wh[l], b[l + 1], h);
+    }
 };
 // weight holders whose hidden_relu(l, h) returns the POST-activation of hidden layer l + 2
 template <typename T, typename = void> struct applies_relu { static constexpr bool value = false; };
@@ -312,31 +322,21 @@ __device__ __forceinline__ void mlp_load(MlpRegs<R, NL> &W, const R *__restrict_
     for (int l = 0; l < NL - 1; ++l) {
         const R *row = p + (size_t)j * H;
         if constexpr (sizeof(R) == 4) {
-            // two passes (lanes 0..31, then 32..63) keep the scratch at 8.3 KB per wave, so that LDS does not cap
-            // the residency of the one-wave workgroups
-            R *mine = stage + (lane & 31) * kStageStride;
+            // row-block order (mlp_hidden_blk): lane (r, i) = lane 16 r + i keeps, for w = 0..3 and n = 0..15,
+            //     wh[l][16 w + n] = W_l[16 w + i][16 r + ((i - n) & 15)]
+            // gathered straight from L2 (192 dword loads per lane and trajectory, ~0.5 % of a 241-point solve)
+            (void)stage;
+            (void)row;
+            const int i = lane & 15, r = lane >> 4;
 #pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                const bool active = (lane >> 5) == half;
-                if (active) {
-                    if (H == kMaxH) {
-                        const float4 *r4 = reinterpret_cast<const float4 *>(row);
+            for (int w = 0; w < 4; ++w) {
+                const int u = 16 * w + i;
 #pragma unroll
-                        for (int k = 0; k < kMaxH / 4; ++k) {
-                            const float4 v = r4[k];
-                            mine[4 * k + 0] = v.x; mine[4 * k + 1] = v.y; mine[4 * k + 2] = v.z; mine[4 * k + 3] = v.w;
-                        }
-                    } else {
-#pragma unroll 8
-                        for (int k = 0; k < kMaxH; ++k) mine[k] = ((k < H) ? live : R(0)) * row[(k < H) ? k : H - 1];
-                    }
+                for (int n = 0; n < 16; ++n) {
+                    const int c = 16 * r + ((i - n) & 15);
+                    const bool ok = u < H && c < H;
+                    W.wh[l][16 * w + n] = ok ? p[(size_t)(ok ? u : 0) * H + (ok ? c : 0)] : R(0);
                 }
-                __builtin_amdgcn_wave_barrier();
-                if (active) {
-#pragma unroll
-                    for (int r = 0; r < kMaxH; ++r) W.wh[l][r] = mine[wcol<R>(r, lane)];      // own row, rotated order
-                }
-                __builtin_amdgcn_wave_barrier();
             }
         } else {
             (void)stage;
@@ -465,14 +465,15 @@ __device__ __forceinline__ void rows_replicate(float h, float (&R)[4])
         "s_nop 0\n\t"                                                                                                         \
         "v_permlane32_swap_b32 %[r0], %[r2]\n\t" /* r0 = h0 x 4, r2 = h2 x 4 */                                               \
         "v_permlane32_swap_b32 %[r1], %[r3]\n\t" /* r1 = h1 x 4, r3 = h3 x 4 */                                               \
-        "v_fma_f32 %[a0], %[r0], %[w0_0], %[bias]\n\t"                                                                        \
+        "v_mul_f32 %[a0], %[r0], %[w0_0]\n\t"                                                                                 \
         "v_mul_f32 %[a1], %[r1], %[w1_0]\n\t"                                                                                 \
         "v_mul_f32 %[a2], %[r2], %[w2_0]\n\t"                                                                                 \
         "v_mul_f32 %[a3], %[r3], %[w3_0]\n\t"                                                                                 \
         HODE_MV_ROWS_1_15                                                                                                     \
         "v_add_f32 %[a0], %[a0], %[a1]\n\t"                                                                                   \
         "v_add_f32 %[a2], %[a2], %[a3]\n\t"                                                                                   \
-        "v_add_f32 %[a0], %[a0], %[a2]" TAIL                                                                                  \
+        "v_add_f32 %[a0], %[a0], %[a2]\n\t"                                                                                   \
+        "v_add_f32 %[a0], %[a0], %[bias]" TAIL                                                                                \
         : [r0] "+v"(r0), [r1] "=&v"(r1), [r2] "=&v"(r2), [r3] "=&v"(r3), [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2),      \
           [a3] "=&v"(a3)                                                                                                      \
         : [bias] "v"(bias), HODE_MV_WEIGHTS);                                                                                 \
@@ -484,6 +485,51 @@ __device__ __forceinline__ float mlp_hidden_relu(const float (&w)[kMaxH], float 
     HODE_MV_LAYER("\n\tv_max_f32 %[a0], 0, %[a0]")
 }
 #undef HODE_MV_LAYER
+// ---- one hidden layer WITHOUT row replication (fp32, register kernel) ---------------------------------------------------------
+// Lane (r, i) = lane 16 r + i keeps w[16 w + n] = W[16 w + i][16 r + ((i - n) & 15)]: accumulator a_w of the lane is the part
+// of unit 16 w + i that comes from the lane's OWN 16-lane row of the activation vector, so h in its natural layout (unit per
+// lane) is the DPP operand as it is.  The four accumulators are then added over the rows AND transposed -- row t <- unit
+// 16 t + i -- by two v_permlane16_swap, one v_permlane32_swap and three adds (the trick of hode_solve_fwd_rows.hip inside
+// one wave):   72 vector instructions per layer instead of the 75 of mlp_hidden, no copies, h back in the natural layout.
+// The bias (natural layout: b[16 t + i] on lane (t, i)) is added behind the reduction: (q0 + q1) + (q2 + q3) + b -- the order
+// every fp32 forward kernel of this library uses, so that they stay comparable bit for bit.
+// Hazards: h is a VALU result (the previous layer's v_max): four plain multiplications stand before the first DPP read; every
+// v_permlane*_swap reads accumulators at least two instructions old (the s_nops where nothing else fits).
+template <bool RELU> __device__ __forceinline__ float mlp_hidden_blk(const float (&w)[kMaxH], float bias, float h)
+{
+    float a0, a1, a2, a3;
+#define HODE_BK_ROW(n) \
+    "v_fmac_f32_dpp %[a2], %[h], %[w2_" #n "] row_ror:" #n " row_mask:0xf bank_mask:0xf\n\t" \
+    "v_fmac_f32_dpp %[a3], %[h], %[w3_" #n "] row_ror:" #n " row_mask:0xf bank_mask:0xf\n\t" \
+    "v_fmac_f32_dpp %[a0], %[h], %[w0_" #n "] row_ror:" #n " row_mask:0xf bank_mask:0xf\n\t" \
+    "v_fmac_f32_dpp %[a1], %[h], %[w1_" #n "] row_ror:" #n " row_mask:0xf bank_mask:0xf\n\t"
+#define HODE_BK_W(n) [w0_##n] "v"(w[n]), [w1_##n] "v"(w[16 + n]), [w2_##n] "v"(w[32 + n]), [w3_##n] "v"(w[48 + n])
+#define HODE_BK_BODY(TAIL)                                                                                                    \
+    asm("v_mul_f32 %[a2], %[h], %[w2_0]\n\t"                                                                                  \
+        "v_mul_f32 %[a3], %[h], %[w3_0]\n\t"                                                                                  \
+        "v_mul_f32 %[a0], %[h], %[w0_0]\n\t"                                                                                  \
+        "v_mul_f32 %[a1], %[h], %[w1_0]\n\t"                                                                                  \
+        HODE_BK_ROW(1) HODE_BK_ROW(2) HODE_BK_ROW(3) HODE_BK_ROW(4) HODE_BK_ROW(5) HODE_BK_ROW(6) HODE_BK_ROW(7) HODE_BK_ROW(8)   \
+        HODE_BK_ROW(9) HODE_BK_ROW(10) HODE_BK_ROW(11) HODE_BK_ROW(12) HODE_BK_ROW(13) HODE_BK_ROW(14) HODE_BK_ROW(15)            \
+        "v_permlane16_swap_b32 %[a2], %[a3]\n\t" /* a2 = [u2.q0 u3.q0 u2.q2 u3.q2]   a3 = [u2.q1 u3.q1 u2.q3 u3.q3] */         \
+        "s_nop 0\n\t"                                                                                                         \
+        "v_permlane16_swap_b32 %[a0], %[a1]\n\t" /* a0 = [u0.q0 u1.q0 u0.q2 u1.q2]   a1 = [u0.q1 u1.q1 u0.q3 u1.q3] */         \
+        "v_add_f32 %[a2], %[a2], %[a3]\n\t"      /* rows: u2 q0+q1, u3 q0+q1, u2 q2+q3, u3 q2+q3 */                            \
+        "v_add_f32 %[a0], %[a0], %[a1]\n\t"      /*       u0 q0+q1, u1 q0+q1, u0 q2+q3, u1 q2+q3 */                            \
+        "s_nop 1\n\t"                                                                                                         \
+        "v_permlane32_swap_b32 %[a0], %[a2]\n\t" /* a0 = q0+q1 of u0 u1 u2 u3, a2 = q2+q3 of u0 u1 u2 u3 (u_t in row t) */     \
+        "v_add_f32 %[a0], %[a0], %[a2]\n\t"                                                                                   \
+        "v_add_f32 %[a0], %[a0], %[bias]" TAIL                                                                                \
+        : [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2), [a3] "=&v"(a3)                                                      \
+        : [h] "v"(h), [bias] "v"(bias), HODE_BK_W(0), HODE_BK_W(1),                                                           \
+          HODE_BK_W(2), HODE_BK_W(3), HODE_BK_W(4), HODE_BK_W(5), HODE_BK_W(6), HODE_BK_W(7), HODE_BK_W(8), HODE_BK_W(9),      \
+          HODE_BK_W(10), HODE_BK_W(11), HODE_BK_W(12), HODE_BK_W(13), HODE_BK_W(14), HODE_BK_W(15));
+    if constexpr (RELU) { HODE_BK_BODY("\n\tv_max_f32 %[a0], 0, %[a0]") } else { HODE_BK_BODY("") }
+#undef HODE_BK_BODY
+#undef HODE_BK_W
+#undef HODE_BK_ROW
+    return a0;
+}
 // acc[q] += sum_n row_ror:n(R[q]) * w[16 q + n], n ascending within each accumulator; R[] must be two wait states old
 __device__ __forceinline__ void rot_matvec64(const float (&w)[kMaxH], const float (&R)[4], float (&acc)[4])
 {
@@ -550,9 +596,9 @@ __device__ __forceinline__ float mlp_hidden_lds(const float4 *__restrict__ img, 
 {
     float R[4];
     rows_replicate(h, R);
-    float acc[4] = {bias, 0.f, 0.f, 0.f};
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
     mlp_hidden_lds_step<0>(img, lane, R, acc);
-    return (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    return ((acc[0] + acc[1]) + (acc[2] + acc[3])) + bias;      // bias last: the order of every fp32 forward kernel
 }
 template <int NL, int NREG> struct MlpLds {
     static_assert(NREG >= 0 && NREG <= ((NL > 1) ? NL - 1 : 0), "NREG counts hidden matrices");

@@ -18,8 +18,8 @@
 // trajectory (solve_one, hode_solve_body.h).  128 VGPRs, no scratch: four waves per SIMD; the 4 096-patient batch is
 // 1 024 workgroups = 4 per CU.
 //
-// The partial sums are combined in the order of the register kernel's four accumulators, (P0 + P1) + (P2 + P3), bias in
-// P0: results are BIT-IDENTICAL to hode_solve_fwd.hip (tests/test_hip_parity.py).
+// The partial sums are combined in the order of the register kernel, ((P0 + P1) + (P2 + P3)) + bias: results are
+// BIT-IDENTICAL to hode_solve_fwd.hip (tests/test_hip_parity.py).
 //
 // Lock step.  A layer needs all four waves, so the four trajectories evaluate their right-hand sides in rounds: every RHS
 // evaluation is one round = a flag exchange (who is still integrating) + NL - 1 layer exchanges.  A wave whose trajectory
@@ -89,7 +89,7 @@ template <int NL> struct MlpQuad {
 #pragma unroll
         for (int t = 0; t < kQuad; ++t) {
             R[t] = xh[t * kWave + p16];            // row `wave` of trajectory t's activation, replicated over the four rows
-            acc[t] = (wave == 0) ? b[l + 1] : 0.f;  // the bias rides in the first quarter, as in the register kernel
+            acc[t] = 0.f;
         }
         asm volatile("" : "+v"(R[0]), "+v"(R[1]), "+v"(R[2]), "+v"(R[3]));
         quarter<0>(wq[l], R, acc);
@@ -105,7 +105,7 @@ template <int NL> struct MlpQuad {
         P[1] = (wave == 1) ? acc[1] : P[1];
         P[2] = (wave == 2) ? acc[2] : P[2];
         P[3] = (wave == 3) ? acc[3] : P[3];
-        return (P[0] + P[1]) + (P[2] + P[3]);
+        return ((P[0] + P[1]) + (P[2] + P[3])) + b[l + 1];      // bias last: the order of every fp32 forward kernel
     }
 
     template <int N> static __device__ __forceinline__ void quarter(const float (&w)[16], const float (&R)[kQuad], float (&acc)[kQuad])

@@ -15,7 +15,7 @@
 // With the four trajectories' vectors H[0..3] in four registers a layer is
 //     64 FMAs      acc[t] += row_ror:n(H[t]) * wq[l][n]                (t = 0..3, n = 0..15; every weight used four times)
 //     3 swaps + 3 adds   the partial sums of the four rows are added AND transposed: row t ends with trajectory t's sums
-//                        ((q0 + q1) + (q2 + q3), the register kernel's order; the bias rides in block 0)
+//                        ((q0 + q1) + (q2 + q3) + bias, the register kernel's order)
 //     relu, one ds_write_b32: row t, lanes i -> xh[t][16 w + i]        (the natural layout of the next layer's input)
 //     one barrier, four ds_read_b32: H[t] = xh[t][lane]
 // Everything else -- first / last layer, mechanistic terms, Runge-Kutta algebra, step-size control, output staging -- stays
@@ -49,7 +49,7 @@ template <int NL> struct MlpRows {
     float w5r[8];
     float b5;
     float wq[(NL > 1) ? NL - 1 : 1][16];      // wq[l][n] on lane (r, i) = W_l[16 wave + i][16 r + ((i - n) & 15)]
-    float bq[(NL > 1) ? NL - 1 : 1];          // b_{l+1}[16 wave + i] on the lanes of row 0, zero elsewhere
+    float bq[(NL > 1) ? NL - 1 : 1];          // b_{l+1}[16 wave + i] (every row: the bias is added behind the row reduction)
     float *xh;                                 // LDS [2][4][kXhStride]
     int *flags;                                // LDS [2][4]
     int lane, wave;
@@ -73,7 +73,7 @@ template <int NL> struct MlpRows {
                 wq[l][n] = ok ? Wl[(size_t)(ok ? j : 0) * Hd + (ok ? col : 0)] : 0.f;
             }
             Wl += (size_t)Hd * Hd;
-            bq[l] = (r == 0 && j < Hd) ? Wl[(j < Hd) ? j : 0] : 0.f;
+            bq[l] = (j < Hd) ? Wl[(j < Hd) ? j : 0] : 0.f;
             Wl += Hd;
         }
         buf = 0;
@@ -117,7 +117,7 @@ template <int NL> struct MlpRows {
             any_active = first_lane(f[0] | f[1] | f[2] | f[3]) != 0;
             buf ^= 1;
         }
-        float acc[kRowsWaves] = {bq[l], bq[l], bq[l], bq[l]};
+        float acc[kRowsWaves] = {0.f, 0.f, 0.f, 0.f};
         fma64(wq[l], acc);
         // add the four rows' partial sums and transpose: row t <- trajectory t
         auto s01 = __builtin_amdgcn_permlane16_swap((unsigned)f2i(acc[0]), (unsigned)f2i(acc[1]), false, false);
@@ -125,7 +125,7 @@ template <int NL> struct MlpRows {
         const float u01 = i2f((int)s01[0]) + i2f((int)s01[1]);   // rows: [t0 q0+q1, t1 q0+q1, t0 q2+q3, t1 q2+q3]
         const float u23 = i2f((int)s23[0]) + i2f((int)s23[1]);   //       [t2 q0+q1, t3 q0+q1, t2 q2+q3, t3 q2+q3]
         auto sw = __builtin_amdgcn_permlane32_swap((unsigned)f2i(u01), (unsigned)f2i(u23), false, false);
-        const float pre = i2f((int)sw[0]) + i2f((int)sw[1]);       // row t: (q0 + q1) + (q2 + q3) of trajectory t
+        const float pre = (i2f((int)sw[0]) + i2f((int)sw[1])) + bq[l];   // row t: (q0 + q1) + (q2 + q3) + b of trajectory t
         float *x = xh + buf * (kRowsWaves * kXhStride);
         x[(lane >> 4) * kXhStride + 16 * wave + (lane & 15)] = rmax0(pre);
         __syncthreads();
