@@ -221,6 +221,7 @@ template <bool RELU> __device__ __forceinline__ double mlp_hidden_blk(const doub
 __device__ __forceinline__ double mlp_hidden_relu(const double (&w)[64], double bias, double h);
 template <typename R, int NL> struct MlpRegs {
     R w1[9];                          // W1[j][0..8]
+    R w1g;                            // W1[j][4] + W1[j][7]: the weight of GLP1, which the input row holds twice
     R b[NL];                          // b_l[j]
     R wh[(NL > 1) ? NL - 1 : 1][kMaxH]; // fp64: W_l[j][0..63], l = 2..NL; fp32: the row-block order of mlp_hidden_blk
     R w5[6];                          // Wout[o][j]
@@ -291,6 +292,7 @@ __device__ __forceinline__ void mlp_load_edges(WT &W, const R *__restrict__ p, i
     const int j = (lane < H) ? lane : H - 1;
 #pragma unroll
     for (int i = 0; i < 9; ++i) W.w1[i] = live * p[j * 9 + i];
+    W.w1g = W.w1[4] + W.w1[7];        // input row = [t, G, I, Glu, GLP1, GE, FFA, GLP1, tvns]: the two GLP1 columns act as one
     p += 9 * H;
     W.b[0] = live * p[j];
     p += H;
@@ -315,6 +317,7 @@ __device__ __forceinline__ void mlp_load(MlpRegs<R, NL> &W, const R *__restrict_
     const int j = (lane < H) ? lane : H - 1;
 #pragma unroll
     for (int i = 0; i < 9; ++i) W.w1[i] = live * p[j * 9 + i];
+    W.w1g = W.w1[4] + W.w1[7];        // input row = [t, G, I, Glu, GLP1, GE, FFA, GLP1, tvns]: the two GLP1 columns act as one
     p += 9 * H;
     W.b[0] = live * p[j];
     p += H;
@@ -603,6 +606,7 @@ __device__ __forceinline__ float mlp_hidden_lds(const float4 *__restrict__ img, 
 template <int NL, int NREG> struct MlpLds {
     static_assert(NREG >= 0 && NREG <= ((NL > 1) ? NL - 1 : 0), "NREG counts hidden matrices");
     float w1[9];
+    float w1g;
     float b[NL];
     float w5[6];
     float w5r[8];
@@ -672,6 +676,18 @@ template <int K> __device__ __forceinline__ float state_bcast(float Y)
 #endif
 }
 template <int K> __device__ __forceinline__ double state_bcast(double Y) { return lane_bcast(Y, K); }
+// acc + x_K * w with the broadcast folded into the FMA (fp32: v_fmac_f32_dpp row_newbcast:K) -- for a component only one
+// instruction reads.  Y must be two wait states old (it is the stage state, computed well before the RHS starts).
+template <int K> __device__ __forceinline__ float fmac_state(float acc, float Y, float w);
+#define HODE_FMAC_STATE(K)                                                                                              \
+    template <> __device__ __forceinline__ float fmac_state<K>(float acc, float Y, float w)                             \
+    {                                                                                                                   \
+        asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:" #K " row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(Y), "v"(w));   \
+        return acc;                                                                                                     \
+    }
+HODE_FMAC_STATE(0) HODE_FMAC_STATE(1) HODE_FMAC_STATE(2) HODE_FMAC_STATE(3) HODE_FMAC_STATE(4) HODE_FMAC_STATE(5)
+#undef HODE_FMAC_STATE
+template <int K> __device__ __forceinline__ double fmac_state(double acc, double Y, double w) { return rfma(w, lane_bcast(Y, K), acc); }
 
 // KK with the eight lanes of stage slot s (lanes 8 s .. 8 s + 7) replaced by F.  fp32: the lane mask 0xff << 8 s is scalar
 // arithmetic and feeds v_cndmask_b32 as an SGPR pair -- (lane >> 3) == s costs a shift and a compare on the vector ALU in
@@ -709,7 +725,7 @@ __device__ __forceinline__ R mech_eval(const OdeP<R> &o, R G, R I, R Glu, R GLP1
     R dGlu = -(o.E_max * rdiv(GLP1, o.EC_50 + GLP1)) * w;                          // :129-130
     R dGLP1 = rfma(o.V_max, rdiv(G, o.K_m + G), -(o.k_L * GLP1));                  // :134-135
     const R k_GE = o.k_GE0 * (R(1) - gde);                                         // :139-140
-    R dFFA = rfma(o.p_9 * G, FFA, -rfma(o.p_8 * I, FFA, o.p_7 * FFA));             // :144
+    R dFFA = rfma(o.p_9, G, rfma(-o.p_8, I, -o.p_7)) * FFA;                        // :144  (-p7 - p8 I + p9 G) F
     R dG = rfma(-k_GE, G, rfma(R(0.005), w, rfma(R(-0.01), v, meal)));             // :148-150
     R r = keep_term(c8 == 0, dG, R(0));
     r = keep_term(c8 == 1, dI, r);
@@ -756,7 +772,7 @@ __device__ __forceinline__ R rhs_eval(const WT &W, const OdeP<R> &o, R t, R Y, R
                                       R gde /* Hill term, 0 without GD */, int lane, ACTS *acts)
 {
     const R G = state_bcast<0>(Y), I = state_bcast<1>(Y), Glu = state_bcast<2>(Y), GLP1 = state_bcast<3>(Y),
-            GE = state_bcast<4>(Y), FFA = state_bcast<5>(Y);
+            FFA = state_bcast<5>(Y);
     const int c8 = lane & 7;
     const R mech = mech_eval(o, G, I, Glu, GLP1, FFA, meal, gde, c8);
     // ---- MLP (models/nn_residual.py:138-147): input row [t, G, I, Glu, GLP1, GE, FFA, glp1:=GLP1, tvns]
@@ -765,10 +781,9 @@ __device__ __forceinline__ R rhs_eval(const WT &W, const OdeP<R> &o, R t, R Y, R
     h = rfma(W.w1[1], G, h);
     h = rfma(W.w1[2], I, h);
     h = rfma(W.w1[3], Glu, h);
-    h = rfma(W.w1[4], GLP1, h);
-    h = rfma(W.w1[5], GE, h);
+    h = rfma(W.w1g, GLP1, h);                    // columns 4 and 7 (both GLP1), folded by the loaders
+    h = fmac_state<4>(h, Y, W.w1[5]);            // GE: only the first layer reads it
     h = rfma(W.w1[6], FFA, h);
-    h = rfma(W.w1[7], GLP1, h);
     h = rfma(W.w1[8], tvns, h);
     h = rmax0(h);
     if constexpr (KEEP) acts->put(0, h);

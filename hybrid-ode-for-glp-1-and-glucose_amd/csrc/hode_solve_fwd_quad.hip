@@ -44,6 +44,7 @@ constexpr int kQuad = 4;            // waves = trajectories per workgroup
 
 template <int NL> struct MlpQuad {
     float w1[9];
+    float w1g;
     float b[NL];
     float w5[6];
     float w5r[8];

@@ -44,6 +44,7 @@ constexpr int kXhStride = 80;       // floats per trajectory in the exchange are
 
 template <int NL> struct MlpRows {
     float w1[9];
+    float w1g;
     float b[NL];
     float w5[6];
     float w5r[8];
