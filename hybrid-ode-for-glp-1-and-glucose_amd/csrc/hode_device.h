@@ -1,11 +1,12 @@
 // hode_device.h -- device-side building blocks shared by all kernels (gfx950 / CDNA4 only).
 //
 // Execution model used throughout: ONE TRAJECTORY PER WAVEFRONT, ONE HIDDEN UNIT PER LANE.
-//   * lane j keeps row j of every hidden weight matrix in VGPRs (weights are loaded once per
-//     trajectory and stay register-resident for all ~1440 RHS evaluations);
-//   * a 64x64 layer is 64 FMAs per lane; the activation of lane k reaches lane j as the DPP
-//     row_ror:n operand of the FMA itself ("rotating operand", see mlp_hidden) -- no v_readlane per
-//     element, no LDS round trip, no barrier;
+//   * the hidden weight matrices live in VGPRs, 64 registers per matrix and lane (loaded once per trajectory, register-
+//     resident for all ~1440 RHS evaluations); activations are kept one unit per lane;
+//   * a 64x64 layer is 64 FMAs per lane; the activation of lane k reaches lane j as the DPP row_ror:n operand of the FMA
+//     itself ("rotating operand") -- no v_readlane per element, no LDS round trip, no barrier.  fp32 forward kernels: lane
+//     16 r + i keeps W[16 w + i][16 r + ((i - n) & 15)] and reduces four row-partial accumulators with a 3-swap transpose
+//     (mlp_hidden_blk); the adjoint and the LDS-image experiment replicate the 16-lane rows first (rows_replicate);
 //   * the 6-vector state is replicated per 8-lane group (lane l holds component l & 7) and the
 //     Runge-Kutta stage derivatives are packed into ONE VGPR (lanes 8s..8s+7 = stage s), so a stage
 //     combination is one multiply by a per-lane coefficient row + a 7-instruction cross-lane sum;
@@ -212,7 +213,7 @@ template <typename R> __device__ __forceinline__ void tableau_rowsT_store(R *row
 
 // ------------------------------------------------------------------------------------------
 // MLP parameters of ONE parameter set, register-resident.  NL = number of hidden layers (1..4).
-// Lane j owns hidden unit j of every layer.  H < 64 is zero-padded (relu(0) = 0 keeps it exact).
+// Activations: lane j = hidden unit j of every layer.  H < 64 is zero-padded (relu(0) = 0 keeps it exact).
 __device__ __forceinline__ float mlp_hidden(const float (&w)[64], float bias, float h);
 __device__ __forceinline__ double mlp_hidden(const double (&w)[64], double bias, double h);
 __device__ __forceinline__ float mlp_hidden_relu(const float (&w)[64], float bias, float h);
