@@ -11,7 +11,10 @@ pytestmark = pytest.mark.gpu
 
 from oracle import oracle as O  # noqa: E402  (checker only)
 
-SHAPES = [(128, 5), (96, 6), (64, 5), (100, 2), (128, 8), (7, 5)]
+SHAPES = [(128, 5), (96, 6), (64, 5), (100, 2), (128, 8), (7, 5),
+          # widths that are not multiples of 16 INSIDE the register-resident envelope (H <= 64, L <= 4): the bounded weight
+          # gathers of the row-block order (mlp_hidden_blk) and of the rotating output layer (out_rot_fill)
+          (40, 3), (7, 2), (33, 4)]
 
 
 def rel(a, b, floor=1e-3):
