@@ -1,0 +1,38 @@
+"""Host-side pieces of bench.py that need no GPU: the kernel-source hash that stamps profiles/pmc_traffic.json."""
+import os
+import shutil
+
+import bench
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_comment_stripper_keeps_code_and_string_literals():
+    src = 'int a = 1; // trailing\n/* block\n comment */ const char *s = "// not a comment"; char c = \'"\';\n'
+    out = bench._strip_c_comments(src)
+    assert "trailing" not in out and "block" not in out
+    assert '"// not a comment"' in out and "int a = 1;" in out and "'\"'" in out
+
+
+def test_kernel_source_hash_ignores_comments_but_not_code(tmp_path):
+    pkg = os.path.join("hybrid-ode-for-glp-1-and-glucose_amd", "csrc")
+    dst = tmp_path / pkg
+    shutil.copytree(os.path.join(ROOT, pkg), dst, ignore=shutil.ignore_patterns("_obj", "*.o", ".build.lock"))
+    base = bench.kernel_source_sha(str(tmp_path))
+    assert base == bench.kernel_source_sha()                      # same sources, other root
+    f = dst / "hode_solve_fwd.hip"
+    text = f.read_text()
+    f.write_text("// a new comment line\n" + text.replace("namespace hode {", "namespace hode {   /* remark */", 1))
+    assert bench.kernel_source_sha(str(tmp_path)) == base         # comments and white space do not count
+    f.write_text(text.replace("dim3(64)", "dim3(64 )", 1).replace("return HODE_EUNSUPPORTED;", "return HODE_EUNSUPPORTED + 0;", 1))
+    assert bench.kernel_source_sha(str(tmp_path)) != base         # code does
+
+
+def test_committed_pmc_stamp_matches_the_committed_kernels():
+    """profiles/pmc_traffic.json must have been taken on the kernels of this tree (bench.py drops the reading otherwise)."""
+    import json
+
+    import pytest
+    stamp = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["kernel_source_sha"]
+    if stamp != bench.kernel_source_sha():      # a reminder, not a gate: kernels may change in a container without a GPU
+        pytest.skip("profiles/pmc_traffic.json is stale: re-run tools/profile_gpu.sh + tools/summarize_profile.py on the GPU box")

@@ -582,9 +582,10 @@ def test_cfg4_65536_cohort_and_its_8_rank_shards(hode):
 
 
 def test_fwd_experiment_kernels_are_bitwise_the_register_kernel(hode, golden_dir, g0, tmp_path):
-    """HODE_FWD=wg (hidden matrices in a shared LDS image, 16 waves per workgroup; hode_solve_fwd_wg.hip) runs the same
-    arithmetic in the same order as the production kernel: identical bits, with and without a tape, ragged batch,
-    two parameter sets.  (The switch is read once per process, so the variant runs in a child process.)"""
+    """The experiment kernels -- HODE_FWD=wg (hidden matrices in a shared LDS image, 16 waves per workgroup), quad (four
+    trajectories per four waves, column split) and rows (row / input-block split) -- run the same arithmetic in the same
+    order as the production kernel: identical bits, with and without a tape, ragged batch, two parameter sets.  (The switch
+    is read once per process, so every variant runs in a child process.)"""
     import subprocess
     import sys
     g = np.load(os.path.join(golden_dir, "g4_t61_pulses.npz"))
