@@ -77,6 +77,10 @@ template <typename R> __device__ __forceinline__ R xlane_xor4(R v)
     return dpp_mov<0x114, 0xA, false>(t, v);  // row_shr:4 into banks 1,3  (lane i <- i-4)
 }
 template <typename R> __device__ __forceinline__ R xlane_xor8(R v) { return dpp_mov<0x128, 0xF, true>(v, v); }  // row_ror:8
+// value of lane (l ^ 7) within each 8-lane half row (row_half_mirror).  For a value that is already uniform over the quads
+// -- a sum after the xor1 / xor2 exchanges -- this IS the other quad's value, in one DPP operand instead of the two masked
+// moves + copy of xlane_xor4.
+template <typename R> __device__ __forceinline__ R xlane_hmirror(R v) { return dpp_mov<0x141, 0xF, true>(v, v); }
 
 // v(l) + v(l ^ 16) and v(l) + v(l ^ 32) on every lane: gfx950 v_permlane16_swap / v_permlane32_swap
 __device__ __forceinline__ float allsum_x16(float v)
@@ -113,7 +117,7 @@ template <typename R> __device__ __forceinline__ R wave_allsum(R v)
 {
     v += xlane_xor1(v);
     v += xlane_xor2(v);
-    v += xlane_xor4(v);
+    v += xlane_hmirror(v);          // quad-uniform by now
     v += xlane_xor8(v);
     v = allsum_x16(v);
     return allsum_x32(v);
@@ -123,7 +127,7 @@ template <typename R> __device__ __forceinline__ R oct_allsum(R v)
 {
     v += xlane_xor1(v);
     v += xlane_xor2(v);
-    v += xlane_xor4(v);
+    v += xlane_hmirror(v);          // quad-uniform by now
     return v;
 }
 
