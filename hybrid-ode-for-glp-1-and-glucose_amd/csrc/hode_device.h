@@ -152,7 +152,14 @@ template <typename R> __device__ __forceinline__ R wave_reduce6_to_lanes(const R
 // sum over the 8 lanes that share (lane & 7), result on all of them
 template <typename R> __device__ __forceinline__ R group_sum8(R v)
 {
-    v += xlane_xor8(v);
+    if constexpr (sizeof(R) == 4) {
+        // v + row_ror:8(v) as ONE instruction (hipcc otherwise re-fuses the producer of v into a copy + v_fmac pair)
+        float t = v;
+        asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf" : "+v"(t));
+        v = t;
+    } else {
+        v += xlane_xor8(v);
+    }
     v = allsum_x16(v);
     return allsum_x32(v);
 }
@@ -312,6 +319,7 @@ __device__ __forceinline__ void mlp_load_edges(WT &W, const R *__restrict__ p, i
     out_rot_fill(W, p, H, lane);
     p += 6 * H;
     W.b5 = ((lane & 7) < 6) ? p[((lane & 7) < 6) ? (lane & 7) : 0] : R(0);   // replicated per 8-lane group
+    if constexpr (sizeof(R) == 4) W.b5 = (lane < 8) ? W.b5 : R(0);            // fp32: enters out_rot once, before the row sums
 }
 
 template <typename R, int NL>
@@ -369,6 +377,7 @@ __device__ __forceinline__ void mlp_load(MlpRegs<R, NL> &W, const R *__restrict_
     out_rot_fill(W, p, H, lane);
     p += 6 * H;
     W.b5 = ((lane & 7) < 6) ? p[((lane & 7) < 6) ? (lane & 7) : 0] : R(0);   // replicated per 8-lane group
+    if constexpr (sizeof(R) == 4) W.b5 = (lane < 8) ? W.b5 : R(0);            // fp32: enters out_rot once, before the row sums
 }
 
 // ------------------------------------------------------------------------------------------
@@ -742,11 +751,11 @@ __device__ __forceinline__ R mech_eval(const OdeP<R> &o, R G, R I, R Glu, R GLP1
 
 // the output layer of out_rot_fill: 1 v_mul + 7 v_fmac_f32_dpp on h (natural layout; the s_nop gives the DPP read of h its
 // second wait state after the v_max that produced it), the row_ror:8 add of the two half sums, the all-reduce over the rows.
-__device__ __forceinline__ float out_rot(const float (&w)[8], float h)
+__device__ __forceinline__ float out_rot(const float (&w)[8], float b5m, float h)
 {
     float a, t;
 #define HODE_OR(n) "v_fmac_f32_dpp %[a], %[h], %[w" #n "] row_ror:" #n " row_mask:0xf bank_mask:0xf\n\t"
-    asm("v_mul_f32 %[a], %[h], %[w0]\n\t"
+    asm("v_fma_f32 %[a], %[h], %[w0], %[b]\n\t"     // b = bout[o] on lanes 0..7 only: it passes the reductions once
         "s_nop 0\n\t"
         HODE_OR(1) HODE_OR(2) HODE_OR(3) HODE_OR(4) HODE_OR(5) HODE_OR(6) HODE_OR(7)
         "s_nop 1\n\t"
@@ -760,8 +769,8 @@ __device__ __forceinline__ float out_rot(const float (&w)[8], float h)
         "v_permlane32_swap_b32 %[a], %[t]\n\t"       // a = [r0+r1 x4], t = [r2+r3 x4]
         "v_add_f32 %[a], %[a], %[t]"
         : [a] "=&v"(a), [t] "=&v"(t)
-        : [h] "v"(h), [w0] "v"(w[0]), [w1] "v"(w[1]), [w2] "v"(w[2]), [w3] "v"(w[3]), [w4] "v"(w[4]), [w5] "v"(w[5]), [w6] "v"(w[6]),
-          [w7] "v"(w[7]));
+        : [h] "v"(h), [b] "v"(b5m), [w0] "v"(w[0]), [w1] "v"(w[1]), [w2] "v"(w[2]), [w3] "v"(w[3]), [w4] "v"(w[4]), [w5] "v"(w[5]),
+          [w6] "v"(w[6]), [w7] "v"(w[7]));
 #undef HODE_OR
     return a;
 }
@@ -798,10 +807,13 @@ __device__ __forceinline__ R rhs_eval(const WT &W, const OdeP<R> &o, R t, R Y, R
         else h = rmax0(W.hidden(l, h));
         if constexpr (KEEP) acts->put(l + 1, h);
     }
-    R nn;
     if constexpr (sizeof(R) == 4) {
-        nn = out_rot(W.w5r, h);
-    } else {
+        // out_rot leaves Wout h + bout on the lanes of slot c8 < 6 and exact zeros on slots 6, 7 (zero weights, zero bias);
+        // the mechanistic select chain ends in zero there as well: no final select
+        return mech + out_rot(W.w5r, W.b5, h);
+    }
+    R nn;
+    {
         R p[6];
 #pragma unroll
         for (int q = 0; q < 6; ++q) p[q] = W.w5[q] * h;
