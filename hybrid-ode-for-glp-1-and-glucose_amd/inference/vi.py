@@ -10,6 +10,11 @@ Same constructor, methods, return values, history / checkpoint layout.  What dif
   gradient of the likelihood reaches mu / log_sigma through the adjoint kernel; `model.adjoint = False` reproduces the
   reference's detached behaviour exactly (tests pin both against values captured from the reference).
 * `posterior_predictive`: all draws in one launch (`forward_param_sets`).
+* `train()` with a validation loader: the reference stores `self.best_state = self.variational_params.state_dict()`
+  (vi.py:236) -- references to the LIVE tensors -- so its closing `load_state_dict(self.best_state)` (:259-260) is a no-op and
+  training ends with the last epoch's posterior.  The mirror clones the state and restores the best validation epoch;
+  `restore_best=False` reproduces the reference (aliasing and all).  tests/test_host_surface.py pins both.
+* `prior_params` is accepted and ignored, as in the reference (vi.py:26-52): the priors live in `model.variational_params`.
 """
 import logging
 from typing import Dict, List, Optional, Tuple
@@ -21,8 +26,9 @@ logger = logging.getLogger(__name__)
 
 class VariationalInference:
     def __init__(self, model, prior_params: Optional[Dict[str, Dict[str, float]]] = None, learning_rate: float = 1e-3,
-                 device: Optional[torch.device] = None):
+                 device: Optional[torch.device] = None, restore_best: bool = True):
         self.model = model
+        self.restore_best = restore_best
         self.device = device or torch.device("cuda" if torch.cuda.is_available() else "cpu")
         self.learning_rate = learning_rate
         if not hasattr(model, "variational_params") or model.variational_params is None:
@@ -94,7 +100,8 @@ class VariationalInference:
                     va[k] /= max(len(val_loader), 1)
                 if va["elbo"] > best_val_elbo:
                     best_val_elbo, patience = va["elbo"], 0
-                    self.best_state = {k: v.detach().clone() for k, v in self.variational_params.state_dict().items()}
+                    sd = self.variational_params.state_dict()
+                    self.best_state = {k: v.detach().clone() for k, v in sd.items()} if self.restore_best else sd
                 else:
                     patience += 1
                 if patience >= early_stopping_patience:
