@@ -27,6 +27,10 @@ import sys
 import time
 from concurrent.futures import ThreadPoolExecutor
 
+# dmabuf IPC is the only mode the host driver supports (RCCL / device-tensor sharing across processes): the default has to be
+# in the environment before anything initialises the HIP runtime, i.e. before torch is even imported
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "hybrid-ode-for-glp-1-and-glucose_amd"))
 sys.path.insert(0, ROOT)
@@ -39,7 +43,8 @@ H, L, T = 64, 4, 241
 FLOP_PER_RHS = 2 * (9 * 64 + 3 * 64 * 64 + 6 * 64) + 80      # 26 576: MLP MACs x2 + mechanistic terms
 FLOP_PER_STEP_ALGEBRA = 400                                   # stage sums, error norm, controller
 BYTES_FWD_PER_TRAJ = 24 + 964 + 964 + 241 * 6 * 4            # x0 + meal row + tVNS row + y  = 7 736 B
-BYTES_TRAIN_PER_TRAJ = 21_300
+BYTES_BWD_PER_TRAJ = 2 * 241 * 6 * 4 + 2 * 964 + 24          # y + dLoss/dy + meal/tVNS rows + gx0 = 13 520 B
+BYTES_TRAIN_PER_TRAJ = BYTES_FWD_PER_TRAJ + BYTES_BWD_PER_TRAJ  # 21 256 B
 PEAK_FP32_TFLOPS = 157.3                                      # MI355X_MICROARCH.md: fp32 vector == f32-MFMA dense peak
 PEAK_FP64_TFLOPS = 78.6                                       # fp64 vector = half the fp32 vector rate (MI355X data sheet; the guide lists fp32 only)
 PEAK_HBM_GBS = 8000.0
@@ -86,23 +91,24 @@ def measured_traffic(key):
     return d.get(key), d.get("source")
 
 
-def ensure_built():
-    """Fresh checkout (built artefacts are git-ignored): build BEFORE any GPU / collective call.  Every rank takes the
-    same path: an exclusive file lock, then `make` (a no-op when up to date; the Makefile links to a temporary name and
-    renames it, so no rank can dlopen a half-written library)."""
-    import fcntl
+def ensure_built(may_build=True):
+    """Build BEFORE any GPU / collective call when libhode.so is missing OR was linked from other sources than the ones in this
+    tree (csrc/Makefile stamps the binary with a hash of its sources; hode/_build.py compares) -- a stale binary is never
+    benchmarked.  Every rank takes the same path: an exclusive file lock, then `make` (the Makefile links to a temporary name
+    and renames it, so no rank can dlopen a half-written library).  may_build=False (--no-build / HODE_NO_BUILD=1; every
+    invocation under rocprofv3, where the profiler's tool library has initialised the GPU before Python starts and a child
+    process must not be spawned): a missing or stale artefact is an error instead."""
     import subprocess
-    pkg = os.path.join(ROOT, "hybrid-ode-for-glp-1-and-glucose_amd")
-    with open(os.path.join(pkg, "csrc", ".build.lock"), "w") as lk:
-        fcntl.flock(lk, fcntl.LOCK_EX)
-        try:
-            if not os.path.exists(os.path.join(pkg, "hode", "libhode.so")):
-                subprocess.run(["make", "-C", os.path.join(pkg, "csrc"), "-j4", "ARCH=gfx950"], check=True,
-                               stdout=subprocess.DEVNULL)
-            if not os.path.exists(os.path.join(ROOT, "oracle", "_build", "libhode_oracle.so")):
-                subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "-s"], check=True, stdout=subprocess.DEVNULL)
-        finally:
-            fcntl.flock(lk, fcntl.LOCK_UN)
+    from hode import _build
+    _build.ensure(may_build=may_build)
+    osoname = os.path.join(ROOT, "oracle", "_build", "libhode_oracle.so")
+    srcs = [os.path.join(ROOT, "oracle", f) for f in ("hode_oracle.c", "hode_oracle_impl.h", "fourgi_oracle.c")]
+    if not os.path.exists(osoname) or any(os.path.getmtime(f) > os.path.getmtime(osoname) for f in srcs if os.path.exists(f)):
+        if not may_build:
+            if not os.path.exists(osoname):
+                raise SystemExit(f"{osoname} is missing and --no-build was given: run `make -C oracle` first")
+            return
+        subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "-s"], check=True, stdout=subprocess.DEVNULL)
 
 
 def synth_weights(seed=0):
@@ -304,7 +310,8 @@ def data_side(dev, B, cpu=True):
     gen = out["generate"]
     traffic, src = measured_traffic("fourgi_generate_hbm_bytes_per_launch")
     gen["roofline_hbm"] = {"bound": "hbm", "achieved": gen["algorithmic_bytes"] / ms_gen / 1e6, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                           "frac": gen["algorithmic_bytes"] / ms_gen / 1e6 / PEAK_HBM_GBS, "traffic": traffic, "traffic_source": src}
+                           "frac": gen["algorithmic_bytes"] / ms_gen / 1e6 / PEAK_HBM_GBS, "traffic": traffic,
+                           "traffic_source": None if traffic is None else f"{src}; this leg's workload: {B} subjects x {T} grid points, fp64"}
     if cpu:
         from oracle import fourgi
         n = 512
@@ -337,6 +344,11 @@ def main():
     ap.add_argument("--no-vi", action="store_true")
     ap.add_argument("--vi-patients", type=int, default=8192, help="patients of the VI leg (BASELINE config 5: 8 192 per GPU x 16 draws)")
     ap.add_argument("--cohort", type=int, default=65536, help="subjects of the data-side leg (4GI generator + windows)")
+    ap.add_argument("--no-zscore", action="store_true", help="skip the z-scored-regime leg (profiling: the headline kernel's "
+                    "launches are then all the benchmark workload, so rocprofv3's average IS ms_per_step)")
+    ap.add_argument("--no-build", action="store_true", help="never spawn make (profiler runs); missing / stale artefacts are errors")
+    ap.add_argument("--total-patients", type=int, default=0, help="N > 1: shard this many patients over the ranks with "
+                    "hode.train.shard_bounds (uneven shards allowed) instead of --patients-per-gpu each")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, default) | gloo (rehearsal: ranks may share one GPU)")
     args = ap.parse_args()
 
@@ -347,7 +359,7 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.gpus > 1 and world == 1:
         raise SystemExit("for --gpus N > 1 launch with torch.distributed.run (one rank per GPU)")
-    ensure_built()                                   # before any GPU / collective call; every rank takes the same path
+    ensure_built(may_build=not (args.no_build or os.environ.get("HODE_NO_BUILD")))   # before any GPU / collective call
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     ndev = torch.cuda.device_count()
@@ -355,7 +367,6 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)      # "nccl" is RCCL on ROCm
         else:
@@ -363,8 +374,17 @@ def main():
 
     import hode
     hode.load()
-    B = args.patients_per_gpu
-    x0, t, meal, tvns = (v.to(dev) for v in synth_cohort(B, 1000 + rank))
+    if args.total_patients > 0:
+        # one cohort sharded contiguously over the ranks (hode.train.shard_bounds: the first N % world ranks hold one more)
+        B_total = args.total_patients
+        lo, hi = hode.train.shard_bounds(B_total, rank, world)
+        B = hi - lo
+        x0, t, meal, tvns = (v.to(dev) for v in synth_cohort(B_total, 1000))
+        x0, meal, tvns = x0[lo:hi].contiguous(), meal[lo:hi].contiguous(), tvns[lo:hi].contiguous()
+    else:
+        B = args.patients_per_gpu
+        B_total = world * B
+        x0, t, meal, tvns = (v.to(dev) for v in synth_cohort(B, 1000 + rank))
     nn_teacher = synth_weights(0).to(dev)
     ode = ODE_DEFAULT.to(dev)
 
@@ -405,12 +425,12 @@ def main():
     nfev = float(sol.nfev.double().sum())
     nsteps = float(sol.nsteps.double().sum())
     ok = int((sol.status == 0).sum())
-    value = world * B * args.steps / wall
+    value = B_total * args.steps / wall
 
     # ------------------------------------------------------------------ secondary: z-scored regime
     # what GlucoseDataset(normalize=True) actually feeds (train/train_hybrid.py:139): x0 ~ N(0,1)^6
     zs = None
-    if rank == 0:
+    if rank == 0 and not args.no_zscore:
         xz = torch.randn(B, 6, generator=torch.Generator().manual_seed(4242)).to(dev)
         zsol = hode.solve_fwd(xz, t, meal, tvns, None, ode, nn_teacher, H, L, rtol=1e-6, atol=1e-8)
         torch.cuda.synchronize()
@@ -433,7 +453,7 @@ def main():
     if not args.no_train:
         obs, student = train_problem(dev, x0, t, meal, tvns, ode, nn_teacher, rank)
         state = hode.train.TrainState(student.clone())
-        n_glob = world * B * T * 6
+        n_glob = B_total * T * 6
 
         def compute(p):
             ls, gnn, gode, _ = hode.train.hip_loss_and_grads(p, ode, x0, t, meal, tvns, obs, H, L, n_glob, state=state)
@@ -484,11 +504,24 @@ def main():
                                       "frac": fwt_flops / (ms_ft * 1e-3) / 1e12 / PEAK_FP32_TFLOPS, "traffic": tr_fwt,
                                       "hbm": {"achieved": fwt_bytes / (ms_ft * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                               "frac": fwt_bytes / (ms_ft * 1e-3) / 1e9 / PEAK_HBM_GBS, "algorithmic_bytes_per_launch": fwt_bytes}}}
+        # SURVEY 8(d) counts only what a training step HAS to move per trajectory (inputs, y, dLoss/dy, gx0: 7 736 + 13 520 B);
+        # the stage tape is this design's memory-for-compute trade and is reported as such, not hidden in the bytes
+        survey_bytes = B * (BYTES_FWD_PER_TRAJ + BYTES_BWD_PER_TRAJ)
+        step_traffic = (tr_adj or 0) + (tr_fwt or 0)
+        roof["step_hbm_vs_survey_8d"] = {
+            "survey_algorithmic_bytes_per_step": survey_bytes, "tape_inclusive_algorithmic_bytes_per_step": tape_bytes + fwt_bytes,
+            "measured_traffic_per_step": step_traffic or None,
+            "measured_over_survey": (step_traffic / survey_bytes) if step_traffic else None,
+            "tape_inclusive_over_survey": (tape_bytes + fwt_bytes) / survey_bytes,
+            "achieved_on_survey_bytes": {"value": survey_bytes / ((ms_ft + ms_adj) * 1e-3) / 1e9, "unit": "GB/s",
+                                         "frac": survey_bytes / ((ms_ft + ms_adj) * 1e-3) / 1e9 / PEAK_HBM_GBS},
+            "note": "the ratio is the price of taping the stage activations instead of recomputing them (recompute measured 27.5 ms "
+                    "against 7-8 ms); the step stays VALU-bound, the tape streams at < 2 TB/s"}
         train = {"roofline": roof,
                  "metric": "patient-trajectories/s (fwd + adjoint + all-reduce + fused Adam)",
-                 "value": world * B * args.train_steps / float(tw), "ms_per_step": float(tw) / args.train_steps * 1e3,
+                 "value": B_total * args.train_steps / float(tw), "ms_per_step": float(tw) / args.train_steps * 1e3,
                  "steps": args.train_steps, "loss_first_last": [losses[0], losses[-1]],
-                 "collective": "1 x all_reduce(sum) of 13 529 fp32 (54 KB) per step" if world > 1 else "none (1 rank)"}
+                 "collective": "1 x all_reduce(sum) of 13 529 fp64 (108 KB: gradients | loss sum | element count) per step" if world > 1 else "none (1 rank)"}
 
     if rank == 0:
         flops = nfev * FLOP_PER_RHS + nsteps * FLOP_PER_STEP_ALGEBRA
@@ -502,7 +535,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE config[1]: 4096-patient 4GI-style synthetic cohort per GPU, DP5(4) adaptive "
                                    "(rtol 1e-6, atol 1e-8), ODE + 4x64 MLP residual, fp32, forward solve, T=241",
-                       "patients_per_gpu": B, "grid_points": T, "parallelism": f"patients sharded x{world}, no data-path collective",
+                       "patients_per_gpu": B_total / world, "patients_total": B_total, "grid_points": T, "parallelism": f"patients sharded x{world}, no data-path collective",
                        "trajectories_ok": ok, "mean_steps": nsteps / B, "mean_nfev": nfev / B},
             "roofline": {"bound": "valu_fp32", "bound_detail": "fp32 vector FMA issue (MFMA deliberately unused, north_star); peak = "
                          "fp32 vector peak 157.3 TFLOP/s (= the f32 MFMA dense peak)",

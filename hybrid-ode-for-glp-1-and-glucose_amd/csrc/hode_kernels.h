@@ -39,9 +39,13 @@ template <typename R> struct RhsArgs {
 };
 
 template <typename R> int launch_solve_fwd(hipStream_t s, const SolveArgs<R> &a, int L, int method);
-int launch_solve_fwd_wg(hipStream_t s, const SolveArgs<float> &a, int L, int method);   // hode_solve_fwd_wg.hip (fp32, L = 2..4)
-int launch_solve_fwd_quad(hipStream_t s, const SolveArgs<float> &a, int L, int method); // hode_solve_fwd_quad.hip (fp32, L = 2..4)
-int launch_solve_fwd_rows(hipStream_t s, const SolveArgs<float> &a, int L, int method); // hode_solve_fwd_rows.hip (fp32, L = 2..4)
+#ifdef HODE_LAB
+// Experiment kernels (csrc/lab/): compiled into hode/lab/libhode_lab.so only (make lab).  The product
+// library libhode.so is built without HODE_LAB: none of these kernels, no environment-variable dispatch on the call path.
+int launch_solve_fwd_wg(hipStream_t s, const SolveArgs<float> &a, int L, int method);   // lab/hode_solve_fwd_wg.hip (fp32, L = 2..4)
+int launch_solve_fwd_quad(hipStream_t s, const SolveArgs<float> &a, int L, int method); // lab/hode_solve_fwd_quad.hip (fp32, L = 2..4)
+int launch_solve_fwd_rows(hipStream_t s, const SolveArgs<float> &a, int L, int method); // lab/hode_solve_fwd_rows.hip (fp32, L = 2..4)
+#endif
 template <typename R> int launch_solve_bwd(hipStream_t s, const AdjArgs<R> &a, int L, int method);
 template <typename R> int launch_rhs_fwd(hipStream_t s, const RhsArgs<R> &a, int L);
 template <typename R> int launch_rhs_bwd(hipStream_t s, const RhsArgs<R> &a, int L);
@@ -104,12 +108,17 @@ inline size_t tape_stage_offset(int B, int max_steps, size_t elem)
 // reals per stage record: h_1..h_L (tuned path: L rows of 64; generic path: 2 L rows, two hidden units per lane) + 8 for the
 // stage state
 inline size_t tape_slot_elems(int H, int L) { return (size_t)(tuned_shape(H, L) ? L : 2 * L) * 64 + 8; }
-// The split adjoint of the tuned fp32 path (hode_solve_bwd_split.hip; opt-in, HODE_BWD=split) hands the layer cotangents of
-// every stage from its propagation kernel to its accumulation kernel through HBM: delta_1..delta_L (L rows of 64) + {kb[6], t,
-// tVNS} in 8 reals per stage, in a region of the tape behind the stage tape (the tape is the adjoint's workspace: nothing is
-// allocated inside the library).  Without the switch, and for other dtypes / shapes, there is no such region.
+// The split adjoint of the tuned fp32 path (lab/hode_solve_bwd_split.hip; lab library only, HODE_BWD=split) hands the layer
+// cotangents of every stage from its propagation kernel to its accumulation kernel through HBM: delta_1..delta_L (L rows of
+// 64) + {kb[6], t, tVNS} in 8 reals per stage, in a region of the tape behind the stage tape (the tape is the adjoint's
+// workspace: nothing is allocated inside the library).  In the product library, and for other dtypes / shapes, there is no
+// such region.
 inline size_t delta_slot_elems(int L) { return (size_t)L * 64 + 8; }
+#ifdef HODE_LAB
 bool split_adjoint_enabled();       // HODE_BWD=split (hode_solve_bwd.hip); the default is the fused one-kernel adjoint
+#else
+constexpr bool split_adjoint_enabled() { return false; }
+#endif
 inline bool has_delta_tape(size_t elem, int H, int L) { return elem == 4 && tuned_shape(H, L) && L >= 2 && split_adjoint_enabled(); }
 inline size_t tape_delta_offset(int B, int max_steps, size_t elem, int H, int L)
 {
@@ -121,6 +130,8 @@ inline size_t tape_total_bytes(int B, int max_steps, size_t elem, int H, int L)
     const size_t o = tape_delta_offset(B, max_steps, elem, H, L);
     return has_delta_tape(elem, H, L) ? o + (size_t)B * max_steps * 6 * delta_slot_elems(L) * elem : o;
 }
-int launch_solve_bwd_split(hipStream_t s, const AdjArgs<float> &a, int L, int method);   // hode_solve_bwd_split.hip (fp32, tuned shapes)
+#ifdef HODE_LAB
+int launch_solve_bwd_split(hipStream_t s, const AdjArgs<float> &a, int L, int method);   // lab/hode_solve_bwd_split.hip (fp32, tuned shapes)
+#endif
 
 }  // namespace hode

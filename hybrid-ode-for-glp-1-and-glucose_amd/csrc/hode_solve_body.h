@@ -172,9 +172,13 @@ __device__ __forceinline__ void solve_one(const SolveArgs<R> &a, const int b, co
                 const R F = f_at(rfma((R)tab.c[s], hh, t0), Ys, ns * 6 + s);
                 KK = stage_put(KK, F, s);
             }
-            tape_put(t0, hh, true);
-            Y = rfma(hh, group_sum8(rows[7 * kWave + lane] * KK), Y);
+            const R Yn4 = rfma(hh, group_sum8(rows[7 * kWave + lane] * KK), Y);
             nf += 4;
+            // a step whose result is not finite is NOT an accepted step: it never reaches the tape (its grid row is never
+            // written, so the adjoint must not walk its non-finite stage records and poison the batch's shared gradient)
+            if (!(fabsf((float)first_lane(oct_allsum(Yn4))) <= 3.0e38f)) { st = HODE_ST_NONFINITE; break; }
+            tape_put(t0, hh, true);
+            Y = Yn4;
             ns += 1;
         } else {
             if (!have_f) {

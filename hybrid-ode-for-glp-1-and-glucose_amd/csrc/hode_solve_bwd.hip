@@ -304,14 +304,29 @@ __global__ __launch_bounds__(WTREG ? 256 : 64 * kBwdWaves, (sizeof(R) == 4 && !W
     }
 }
 
+// compute units of the current device (one adjoint workgroup per CU); queried once per device, never assumed
+static int device_cu_count()
+{
+    static int cached[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (cached[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
+        cached[dev] = n;
+    }
+    return cached[dev];
+}
+
 template <typename R, int NL, bool GODE, bool WTREG, bool GD> static int launch_bwd_g(hipStream_t s, const AdjArgs<R> &a, int method)
 {
     constexpr int kW = WTREG ? 4 : kBwdWaves;
     const int per_set = a.B / a.n_sets;
-    int blocks = per_set < 256 ? per_set : 256;   // one workgroup per CU, its waves loop over trajectories (wave-major)
+    const int cus = device_cu_count();
+    int blocks = per_set < cus ? per_set : cus;   // one workgroup per CU, its waves loop over trajectories (wave-major)
     // never more workgroups than CUs when that is avoidable: 86 x 3 = 258 would leave two workgroups for a second round
     // that doubles the kernel time
-    if (a.n_sets > 1 && blocks * a.n_sets > 256) blocks = 256 / a.n_sets;
+    if (a.n_sets > 1 && blocks * a.n_sets > cus) blocks = cus / a.n_sets;
     if (blocks < 1) blocks = 1;
     const size_t lds = bwd_lds_elems<R, NL>() * sizeof(R);
     dim3 grid(blocks, a.n_sets), block(64 * kW);
@@ -327,36 +342,40 @@ template <typename R, int NL, bool GODE, bool WTREG> static int launch_bwd_k(hip
     return a.gd_mode != 0 ? launch_bwd_g<R, NL, GODE, WTREG, true>(s, a, method) : launch_bwd_g<R, NL, GODE, WTREG, false>(s, a, method);
 }
 
-// fp32 default: transposed matrices in LDS, 2 waves/SIMD (measured 8.2 ms per 4096x241 adjoint).
-// HODE_BWD_WT=regs selects the register-resident variant (1 wave/SIMD, 13.9 ms) for comparison.
+#ifdef HODE_LAB
+// Lab library only.  HODE_BWD_WT=regs: transposed matrices in registers (1 wave/SIMD, 13.9 ms against 8.2 ms);
+// HODE_BWD=split: the two-kernel adjoint of lab/hode_solve_bwd_split.hip (fp32, L >= 2; 8.8 ms against 8.0 ms at 4 096 x 241,
+// DESIGN.md section 6.2).  Both kept as the reproducible record of those experiments.
 static bool bwd_wt_in_regs()
 {
     static const bool v = [] { const char *e = getenv("HODE_BWD_WT"); return e && e[0] == 'r'; }();
     return v;
 }
-
-template <typename R, int NL> static int launch_bwd_nl(hipStream_t s, const AdjArgs<R> &a, int method)
-{
-    if constexpr (sizeof(R) == 4) {
-        if (bwd_wt_in_regs())
-            return a.gode ? launch_bwd_k<R, NL, true, true>(s, a, method) : launch_bwd_k<R, NL, false, true>(s, a, method);
-    }
-    return a.gode ? launch_bwd_k<R, NL, true, false>(s, a, method) : launch_bwd_k<R, NL, false, false>(s, a, method);
-}
-
-// HODE_BWD=split: the two-kernel adjoint of hode_solve_bwd_split.hip (fp32, L >= 2) instead of the fused kernel above.
-// Measured 8.8 ms against 8.0 ms at 4 096 x 241: kept as the reproducible record of that experiment.
 bool split_adjoint_enabled()
 {
     static const bool v = [] { const char *e = getenv("HODE_BWD"); return e && e[0] == 's'; }();
     return v;
 }
+#endif
+
+template <typename R, int NL> static int launch_bwd_nl(hipStream_t s, const AdjArgs<R> &a, int method)
+{
+#ifdef HODE_LAB
+    if constexpr (sizeof(R) == 4) {
+        if (bwd_wt_in_regs())
+            return a.gode ? launch_bwd_k<R, NL, true, true>(s, a, method) : launch_bwd_k<R, NL, false, true>(s, a, method);
+    }
+#endif
+    return a.gode ? launch_bwd_k<R, NL, true, false>(s, a, method) : launch_bwd_k<R, NL, false, false>(s, a, method);
+}
 
 template <typename R> int launch_solve_bwd(hipStream_t s, const AdjArgs<R> &a, int L, int method)
 {
+#ifdef HODE_LAB
     if constexpr (sizeof(R) == 4) {
         if (L >= 2 && a.tape_delta && split_adjoint_enabled() && !bwd_wt_in_regs()) return launch_solve_bwd_split(s, a, L, method);
     }
+#endif
     switch (L) {
     case 1: return launch_bwd_nl<R, 1>(s, a, method);
     case 2: return launch_bwd_nl<R, 2>(s, a, method);

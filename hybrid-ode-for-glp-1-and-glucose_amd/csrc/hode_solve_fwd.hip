@@ -2,9 +2,8 @@
 //
 // Replaces HybridODENN.forward (reference models/hybrid_ode_nn.py:136-261).  The integration itself is
 // hode_solve_body.h (solve_one).  This kernel -- one wave per workgroup, 211 weight registers, 2 waves per SIMD -- is the
-// production kernel for fp32 and fp64.  HODE_FWD=wg selects the workgroup kernel of hode_solve_fwd_wg.hip instead (hidden
-// matrices in a shared LDS image, 4 waves per SIMD): same bits, measured 8-12 % SLOWER, kept as the
-// reproducible record of that experiment.
+// production kernel for fp32 and fp64.  Three experiment kernels that reach 4 waves per SIMD and measured SLOWER (DESIGN.md
+// section 6.2) live in csrc/lab/ and are compiled into the lab library only.
 #include "hode_solve_body.h"
 #include <cstdlib>
 
@@ -54,9 +53,11 @@ static int launch_nl(hipStream_t s, const SolveArgs<R> &a, int method)
     return hipGetLastError() == hipSuccess ? HODE_OK : HODE_ELAUNCH;
 }
 
-// HODE_FWD=wg: the LDS-image workgroup kernel (hode_solve_fwd_wg.hip); HODE_FWD=quad: four trajectories per four waves with
-// column-split weights (hode_solve_fwd_quad.hip); HODE_FWD=rows: four trajectories per four waves, weights split by output
-// rows over the waves and by input blocks over the 16-lane rows (hode_solve_fwd_rows.hip); HODE_FWD=regs: this file's kernel
+#ifdef HODE_LAB
+// Lab library only (make lab -> hode/lab/libhode_lab.so).  HODE_FWD=wg: the LDS-image workgroup kernel
+// (lab/hode_solve_fwd_wg.hip); HODE_FWD=quad: four trajectories per four waves with column-split weights
+// (lab/hode_solve_fwd_quad.hip); HODE_FWD=rows: four trajectories per four waves, weights split by output rows over the waves
+// and by input blocks over the 16-lane rows (lab/hode_solve_fwd_rows.hip); anything else: this file's kernel
 static char fwd_mode()
 {
     static const char v = [] {
@@ -66,15 +67,17 @@ static char fwd_mode()
     }();
     return v;
 }
-static bool fwd_use_wg() { return fwd_mode() == 'w'; }
+#endif
 
 template <typename R> int launch_solve_fwd(hipStream_t s, const SolveArgs<R> &a, int L, int method)
 {
+#ifdef HODE_LAB
     if constexpr (sizeof(R) == 4) {
-        if (L >= 2 && L <= 4 && fwd_use_wg()) return launch_solve_fwd_wg(s, a, L, method);
+        if (L >= 2 && L <= 4 && fwd_mode() == 'w') return launch_solve_fwd_wg(s, a, L, method);
         if (L >= 2 && L <= 4 && fwd_mode() == 'q') return launch_solve_fwd_quad(s, a, L, method);
         if (L >= 2 && L <= 4 && fwd_mode() == 'R') return launch_solve_fwd_rows(s, a, L, method);
     }
+#endif
     switch (L) {
     case 1: return launch_nl<R, 1>(s, a, method);
     case 2: return launch_nl<R, 2>(s, a, method);

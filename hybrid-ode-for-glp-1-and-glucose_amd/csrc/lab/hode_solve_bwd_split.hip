@@ -20,8 +20,8 @@
 // fused kernel's time goes, and the layer cotangents cross HBM twice more (+12 GB per step).  Lessons kept in the code:
 // vmcnt retires in issue order, so (i) record DMAs must be waited for with a COUNT that leaves the younger delta stores
 // in flight, (ii) with stages this short the DMA ring has to run three records ahead.
-#include "hode_device.h"
-#include "hode_kernels.h"
+#include "../hode_device.h"
+#include "../hode_kernels.h"
 #include <cstdlib>
 
 namespace hode {

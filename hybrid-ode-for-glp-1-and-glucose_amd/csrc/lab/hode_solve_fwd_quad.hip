@@ -33,7 +33,7 @@
 // ~1.0 M trajectories/s, i.e. ~3.8 cycles per VALU instruction and SIMD at the ~2.3 GHz the chip holds: the ceiling is
 // not occupancy, LDS or the DPP rate of one of them but what they share -- ~550 instructions (363 VALU) per RHS and wave
 // through the same instruction front end.
-#include "hode_solve_body.h"
+#include "../hode_solve_body.h"
 #include <cstdlib>
 
 namespace hode {

@@ -32,7 +32,7 @@
 // first exchange.  A wave whose trajectory has finished (or that has none: ragged last workgroup) keeps serving rounds with
 // a zero activation until all four flags are down; all waves leave together.  The exchange area is double-buffered: a wave
 // can be at most one barrier ahead of its partners.
-#include "hode_solve_body.h"
+#include "../hode_solve_body.h"
 #include <cstdlib>
 
 namespace hode {

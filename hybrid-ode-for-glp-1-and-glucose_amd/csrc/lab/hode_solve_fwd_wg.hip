@@ -12,7 +12,7 @@
 // matrices through LDS frees 128-192 registers per wave: 4 waves per SIMD (16 per CU = 16 trajectories per CU, so
 // the 4 096-patient batch is exactly one workgroup per CU).  The arithmetic and its order are those of the register
 // kernel: both give the same bits (tests/test_hip_parity.py::test_fwd_workgroup_kernel_is_bitwise_the_register_kernel).
-#include "hode_solve_body.h"
+#include "../hode_solve_body.h"
 #include <cstdlib>
 
 namespace hode {

@@ -39,6 +39,12 @@ def load():
         if not os.path.exists(_SO):
             raise HodeError(f"{_SO} not found: build it with `python __graft_entry__.py` "
                             "(hipcc --offload-arch=gfx950); there is no CPU fallback for the hot path")
+        if not os.environ.get("HODE_LIB") and not os.environ.get("HODE_ALLOW_STALE"):
+            from . import _build
+            if not _build.is_current():
+                raise HodeError(f"{_SO} was not built from the kernel sources next to it (binary {_build.binary_stamp()}, sources "
+                                f"{_build.source_stamp()}): rebuild with `python __graft_entry__.py` (or `make -C {_build.CSRC}`); "
+                                "HODE_ALLOW_STALE=1 loads it anyway")
         _lib = C.CDLL(_SO)
         _lib.hode_version.restype = C.c_char_p
         _lib.hode_tape_bytes.restype = C.c_size_t

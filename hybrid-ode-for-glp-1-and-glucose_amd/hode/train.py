@@ -2,10 +2,13 @@
 
 Trajectories are independent given the parameters, so the cohort is split contiguously over the
 ranks (one process per GPU).  Every rank integrates its shard, runs the adjoint, and the ranks
-exchange ONE flat fp32 buffer [ MLP grads (P) | ODE-constant grads (17) | loss_sum | n_elements ]
-(~54 KB) through a single all-reduce(sum) -- RCCL over xGMI with backend "nccl" -- then apply the
-identical fused clip+Adam update, so parameters stay bit-identical without a broadcast.
-At 54 KB the collective is latency-bound: it is neither bucketed nor overlapped.
+exchange ONE flat fp64 buffer [ MLP grads (P) | ODE-constant grads (17) | loss_sum | n_elements ]
+(13 529 values, 108 KB) through a single all-reduce(sum) -- RCCL over xGMI with backend "nccl" --
+then apply the identical fused clip+Adam update, so parameters stay bit-identical without a
+broadcast.  fp64 because the tail is not a gradient: the squared-error sum is accumulated in fp64
+by the MSE kernel and the element count of BASELINE config 4 (8 x 8 192 x 241 x 6 = 94.8 M) is
+beyond fp32's 2^24 integers; the gradients ride along (summed in fp64, rounded to fp32 once).
+At 108 KB the collective is latency-bound: it is neither bucketed nor overlapped.
 
 The reference has no distributed code at all; the single-rank semantics
 mirror train/train_hybrid.py:247-261 (loss, backward, clip_grad_norm_ 5.0, Adam).
@@ -48,13 +51,13 @@ class TrainState:
 
 
 def pack(gnn: torch.Tensor, gode: Optional[torch.Tensor], loss_sum: torch.Tensor, n_elem: float) -> torch.Tensor:
-    """[gnn | gode(17) | loss_sum | n_elem] as one fp32 vector (the only message of a step)."""
-    tail = torch.zeros(N_ODE + 2, dtype=torch.float32, device=gnn.device)
+    """[gnn | gode(17) | loss_sum | n_elem] as one fp64 vector (the only message of a step)."""
+    tail = torch.zeros(N_ODE + 2, dtype=torch.float64, device=gnn.device)
     if gode is not None:
-        tail[:N_ODE] = gode.float()
-    tail[N_ODE] = loss_sum.reshape(()).float()
+        tail[:N_ODE] = gode.double()
+    tail[N_ODE] = loss_sum.reshape(()).double()
     tail[N_ODE + 1] = float(n_elem)
-    return torch.cat([gnn.float().reshape(-1), tail])
+    return torch.cat([gnn.double().reshape(-1), tail])
 
 
 def unpack(buf: torch.Tensor, P: int):
@@ -84,19 +87,27 @@ def train_step(state: TrainState, compute: Callable[[torch.Tensor], Tuple[torch.
     collective through host memory (gloo rehearsal of the multi-rank path on a single GPU)."""
     P = state.p.numel()
     loss_sum, gnn, gode, n_local = compute(state.p)
-    buf = pack(gnn, gode, loss_sum, n_local)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        if host_staged:                                               # gloo rehearsal with device tensors
-            host = buf.cpu()
-            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
-            buf.copy_(host)
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+        # one rank: nothing to exchange, no message to build
+        state.step += 1
+        if optimizer is not None:
+            optimizer(state, gnn.float())
         else:
-            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)  # the step's only collective
+            capi.adam_step(state.p, gnn.float().contiguous(), state.m, state.v, lr, betas[0], betas[1], eps, state.step,
+                           max_norm=max_norm, scratch=state.scratch)
+        return loss_sum.reshape(()).double() / float(n_local)
+    buf = pack(gnn, gode, loss_sum, n_local)
+    if host_staged:                                                   # gloo rehearsal with device tensors
+        host = buf.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+        buf.copy_(host)
+    else:
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)      # the step's only collective
     g, _gode, lsum, n_tot = unpack(buf, P)
     state.step += 1
     if optimizer is not None:
-        optimizer(state, g)
+        optimizer(state, g.float())
     else:
-        capi.adam_step(state.p, g.contiguous(), state.m, state.v, lr, betas[0], betas[1], eps, state.step,
+        capi.adam_step(state.p, g.float().contiguous(), state.m, state.v, lr, betas[0], betas[1], eps, state.step,
                        max_norm=max_norm, scratch=state.scratch)
     return lsum / n_tot

@@ -120,8 +120,14 @@ int hode_solve_fwd_f64(void *stream, int B, int T, const double *x0, const doubl
  *      reference detaches the solve; north_star requires it).
  *      gy[B,T,6] = dLoss/dy  ->  gx0[B,6] (written), gnn[n_sets,P] and gode[n_sets,17]
  *      (ACCUMULATED with atomics: zero them first; either may be NULL).  tape: the buffer the forward filled.  It is not
- *      const: with HODE_BWD=split (an experimental two-kernel adjoint) its tail is scratch for the layer cotangents;
- *      what the forward recorded stays intact, the same tape may be walked again.                 */
+ *      const: the adjoint may use its tail as scratch; what the forward recorded stays intact, the same tape may be
+ *      walked again.
+ *      nsteps[b], status[b]: what the forward returned for this tape.  The adjoint walks min(nsteps[b], max_steps) steps:
+ *      a count larger than the tape it is handed (the caller merged the bookkeeping of a re-integration with a larger
+ *      budget, say) is CLAMPED SILENTLY -- never an out-of-bounds read, but then the gradient is that of the truncated
+ *      trajectory; pass the nsteps of the forward call that filled THIS tape.  A trajectory with status != 0 contributes the
+ *      cotangents of the rows it still wrote (rows after the failure are zero in y and their gy is ignored); a non-finite
+ *      step is never on the tape (status 3 trajectories end BEFORE the step that blew up).                  */
 int hode_solve_bwd_f32(void *stream, int B, int T, const float *t, int t_batched,
                        const float *meal, int meal_mode, const float *tvns, int tvns_mode,
                        const float *gd, int gd_mode, const float *ode_p, const float *nn_p,

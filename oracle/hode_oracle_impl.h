@@ -296,13 +296,22 @@ int SFX(hode_oracle_solve)(int B, int T, const REAL *x0, const REAL *tg, int t_b
                 for (int i = 0; i < 6; ++i) yt[i] = yc[i] + hh * k3[i];
                 SFX(seg_eval)(&s, s.t1, &mm, &vv, &dd);
                 SFX(rhs_one)(&m, ode, s.t1, yt, mm, vv, dd, s.use_gd, k4, act);
+                REAL ynew[6];
+                int fin4 = 1;
+                for (int i = 0; i < 6; ++i) {
+                    ynew[i] = yc[i] + hh / (REAL)6 * (k1[i] + (REAL)2 * k2[i] + (REAL)2 * k3[i] + k4[i]);
+                    if (!isfinite((double)ynew[i])) fin4 = 0;
+                }
+                nf += 4;
+                /* a step whose result is not finite is NOT an accepted step: it never reaches the tape (its row is never
+                   written, so the adjoint must not walk its non-finite stage records) -- status 3, rows from here on zero */
+                if (!fin4) { st = 3; break; }
                 if (tape && ns < max_steps) {
                     SFX(tape_t) *e = tape + (size_t)b * max_steps + ns;
                     e->t = tc; e->h = hh; e->seg = k | HODE_SEG_CLOSED; for (int i = 0; i < 6; ++i) e->y[i] = yc[i];
                 }
-                for (int i = 0; i < 6; ++i)
-                    yc[i] += hh / (REAL)6 * (k1[i] + (REAL)2 * k2[i] + (REAL)2 * k3[i] + k4[i]);
-                nf += 4; ns += 1;
+                for (int i = 0; i < 6; ++i) yc[i] = ynew[i];
+                ns += 1;
             } else {
                 if (!have_f) {                       /* first RHS + Hairer initial step (common.py:68-135) */
                     SFX(seg_eval)(&s, tc, &mm, &vv, &dd);

@@ -44,10 +44,11 @@ def pytest_sessionstart(session):
     without a GPU) and the oracle once, exactly as __graft_entry__.build() does.  A failing build is reported by the
     tests that need the library (the product path raises when it is missing), not hidden here."""
     import subprocess
-    so = os.path.join(PKG, "hode", "libhode.so")
-    if not os.path.exists(so):
-        subprocess.run(["make", "-C", os.path.join(PKG, "csrc"), "-j4", "ARCH=gfx950"], check=False,
-                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    try:
+        from hode import _build          # missing OR linked from other sources than the ones in this tree -> make
+        _build.ensure(lab=True, jobs=8)  # + hode/lab/libhode_lab.so: the experiment kernels the bitwise tests compare with
+    except Exception:
+        pass
     if not os.path.exists(os.path.join(ROOT, "oracle", "_build", "libhode_oracle.so")):
         subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "-s"], check=False,
                        stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)

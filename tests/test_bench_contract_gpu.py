@@ -45,7 +45,7 @@ def test_bench_two_ranks_gloo_on_one_gpu_matches_single_process_step():
     assert out["roofline"]["bound"] == "valu_fp32" and 0 < out["roofline"]["frac"] < 1
     assert "cpu_baseline" not in out and "vi_step" not in out      # rank-0-at-N=1 legs only
     tr = out["train_step"]
-    assert tr["collective"].startswith("1 x all_reduce(sum) of 13 529 fp32")
+    assert tr["collective"].startswith("1 x all_reduce(sum) of 13 529 fp64")
     # the same step in ONE process on the union of the two shards: first-step loss of the 2-rank run == global mean loss
     dev = torch.device("cuda")
     nn_t, ode = bench.synth_weights(0).to(dev), bench.ODE_DEFAULT.to(dev)
@@ -58,3 +58,35 @@ def test_bench_two_ranks_gloo_on_one_gpu_matches_single_process_step():
         n += B * 241 * 6
     assert abs(tr["loss_first_last"][0] - tot / n) < 1e-6 * (tot / n)
     assert np.isfinite(tr["value"]) and tr["value"] > 0
+
+
+def test_bench_two_ranks_uneven_shards_is_the_single_process_step_on_the_whole_cohort():
+    """`--total-patients 37` over two ranks = shards of 19 and 18 (hode.train.shard_bounds) through bench.py's own path: the
+    global-mean scaling, the fp64 message and the whole-job value must not assume equal shards."""
+    import bench
+    import hode
+    N = 37
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--backend", "gloo", "--total-patients", str(N), "--train-steps", "2", "--no-zscore"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["config"]["patients_total"] == N and out["config"]["patients_per_gpu"] == N / 2 and "zscore_regime" not in out
+    assert abs(out["value"] - N * 2 / (out["ms_per_step"] * 2e-3)) < 1e-6 * out["value"]
+    dev = torch.device("cuda")
+    nn_t, ode = bench.synth_weights(0).to(dev), bench.ODE_DEFAULT.to(dev)
+    x0, t, meal, tv = (v.to(dev) for v in bench.synth_cohort(N, 1000))
+    tot = 0.0
+    for rank in range(2):
+        lo, hi = hode.train.shard_bounds(N, rank, 2)
+        assert hi - lo == (19 if rank == 0 else 18)
+        obs, student = bench.train_problem(dev, x0[lo:hi].contiguous(), t, meal[lo:hi].contiguous(), tv[lo:hi].contiguous(), ode, nn_t, rank)
+        ls, _, _, _ = hode.train.hip_loss_and_grads(student, ode, x0[lo:hi].contiguous(), t, meal[lo:hi].contiguous(), tv[lo:hi].contiguous(),
+                                                    obs, 64, 4, N * 241 * 6)
+        tot += float(ls)
+    first = out["train_step"]["loss_first_last"][0]
+    assert abs(first - tot / (N * 241 * 6)) < 1e-6 * first

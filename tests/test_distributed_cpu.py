@@ -2,7 +2,7 @@
 
 The HIP kernels cannot run here, so the per-shard compute is INJECTED: the oracle (checker) stands
 in for the forward+adjoint of a shard.  What is under test is the N>1 logic itself: contiguous
-sharding, the single all-reduce(sum) of [grads | ode grads | loss_sum | n], global-mean scaling,
+sharding, the single all-reduce(sum) of the fp64 message [grads | ode grads | loss_sum | n], global-mean scaling,
 and that every rank ends with bit-identical parameters equal to the single-process result.
 """
 import os
@@ -111,9 +111,15 @@ def test_data_parallel_step_matches_single_process(world):
 def test_pack_unpack_and_shards():
     g = torch.arange(5, dtype=torch.float32)
     buf = T.pack(g, torch.ones(17), torch.tensor([3.5], dtype=torch.float64), 42)
-    assert buf.numel() == 5 + 17 + 2 and buf.dtype == torch.float32
+    assert buf.numel() == 5 + 17 + 2 and buf.dtype == torch.float64
     a, b, c, d = T.unpack(buf, 5)
-    assert torch.equal(a, g) and float(b.sum()) == 17 and float(c) == 3.5 and float(d) == 42
+    assert torch.equal(a.float(), g) and float(b.sum()) == 17 and float(c) == 3.5 and float(d) == 42
+    # the tail is not a gradient: BASELINE config 4's element count (8 x 8 192 x 241 x 6) + 1 and a loss sum with 40 significant
+    # bits must survive the message and an 8-way sum exactly
+    n4 = 8192 * 241 * 6
+    msg = sum(T.pack(g, None, torch.tensor([1.0 + 2.0 ** -40], dtype=torch.float64), n4 + (r == 0)) for r in range(8))
+    _, _, ls, n = T.unpack(msg, 5)
+    assert float(n) == 8 * n4 + 1 and float(ls) == 8.0 + 8 * 2.0 ** -40
     for n, w in [(10, 3), (4096, 8), (65536, 8), (7, 8)]:
         b = [T.shard_bounds(n, r, w) for r in range(w)]
         assert b[0][0] == 0 and b[-1][1] == n and all(b[i][1] == b[i + 1][0] for i in range(w - 1))

@@ -37,8 +37,8 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     assert hode.version().startswith("hode ")
     assert lib.hode_nn_param_count(64, 4) == 13510 and lib.hode_nn_param_count(32, 2) == 1574
-    # entries + interval indices + the stage tape (h_1..h_4 + state per stage); HODE_BWD=split adds a delta tape of the same size
-    assert hode.load().hode_tape_bytes(4096, 300, 4, 4) == 4096 * 300 * 36 + (2 if os.environ.get("HODE_BWD", "").startswith("s") else 1) * 4096 * 300 * 6 * (4 * 64 + 8) * 4
+    # entries + interval indices + the stage tape (h_1..h_4 + state per stage)
+    assert hode.load().hode_tape_bytes(4096, 300, 4, 4) == 4096 * 300 * 36 + 4096 * 300 * 6 * (4 * 64 + 8) * 4
     assert hode.load().hode_tape_bytes(4096, 300, 8, 4) == 4096 * 300 * 68 + 4096 * 300 * 6 * (4 * 64 + 8) * 8      # fp64: no delta tape
     # the generic path (H > 64 or L > 4) records two rows of 64 per layer + the state: 2L x 64 + 8 reals per stage
     assert lib.hode_tape_bytes_hl(32, 92, 4, 128, 5) == 32 * 92 * 36 + 32 * 92 * 6 * (10 * 64 + 8) * 4
@@ -363,3 +363,26 @@ def test_vi_train_early_stopping_and_restore_semantics(restore_best):
     assert vi.history["elbo"] == [1.0, 2.0, 3.0, 4.0] and vi.history["kl"] == [0.5] * 4     # the stopping epoch is not logged (vi.py:243-251)
     final = float(vi.variational_params.state_dict()[name].flatten()[0])
     assert final == (2.0 if restore_best else 5.0)
+
+
+def test_product_library_carries_no_experiment_kernels_and_no_env_dispatch():
+    """libhode.so = production kernels only; the experiment kernels of csrc/lab/ and their HODE_FWD / HODE_BWD / HODE_BWD_WT
+    switches exist in hode/lab/libhode_lab.so alone (csrc/Makefile `lab`).  Checked on the binaries: symbol tables and strings."""
+    import subprocess
+    from hode import _build
+    assert _build.is_current()                                    # linked from exactly the sources in this tree
+
+    def text(path):
+        syms = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True).stdout
+        return syms, open(path, "rb").read()
+    syms, blob = text(_build.SO)
+    for marker in (b"HODE_FWD", b"HODE_BWD", b"HODE_BWD_WT"):
+        assert marker not in blob, marker
+    for name in ("solve_fwd_wg", "solve_fwd_quad", "solve_fwd_rows", "solve_bwd_split", "split_adjoint_enabled"):
+        assert name not in syms, name
+    if os.path.exists(_build.LAB_SO):
+        lsyms, lblob = text(_build.LAB_SO)
+        assert b"HODE_FWD" in lblob and b"HODE_BWD" in lblob
+        assert "launch_solve_fwd_wg" in lsyms and "launch_solve_bwd_split" in lsyms
+        for name in hode.capi.SYMBOLS:                            # the lab library is the same C ABI
+            assert name in lsyms, name

@@ -25,10 +25,18 @@ if len(stats) > 1:
              "the run, or the stale files -- the counters of different kernel versions would be averaged together")
 rows = list(csv.DictReader(open(stats[-1])))
 with open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w") as f:
-    f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --train-steps 2 --no-cpu-baseline\n")
+    f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --train-steps 2 --no-cpu-baseline --no-vi --no-zscore --no-build\n")
     f.write("kernel,calls,total_ns,avg_ns,pct,min_ns,max_ns\n")
     for r in rows[:18]:
         f.write(f"\"{short(r['Name'])[:90]}\",{r['Calls']},{r['TotalDurationNs']},{float(r['AverageNs']):.0f},{r['Percentage']},{r['MinNs']},{r['MaxNs']}\n")
+
+zstats = sorted(glob.glob(os.path.join(src, "trace_zscore", "*", "*_kernel_stats.csv")), key=os.path.getmtime)
+if zstats:
+    with open(os.path.join(dst, f"{tag}_kernel_stats_zscore.csv"), "w") as f:
+        f.write("# rocprofv3 --kernel-trace --stats -- python3 tools/zscore_launches.py   (7 launches, x0 ~ N(0,1)^6, 4 096 x 241)\n")
+        f.write("kernel,calls,total_ns,avg_ns,pct,min_ns,max_ns\n")
+        for r in list(csv.DictReader(open(zstats[-1])))[:4]:
+            f.write(f"\"{short(r['Name'])[:90]}\",{r['Calls']},{r['TotalDurationNs']},{float(r['AverageNs']):.0f},{r['Percentage']},{r['MinNs']},{r['MaxNs']}\n")
 
 pmc = collections.defaultdict(dict)
 for fcsv in glob.glob(os.path.join(src, "pmc_*", "*", "*_counter_collection.csv")):
@@ -63,7 +71,9 @@ for k, d in pmc.items():
             if key in k:
                 traffic[f"{key}_hbm_bytes_per_launch"] = d["hbm_bytes_per_launch_corrected"]
 json.dump(out, open(os.path.join(dst, f"{tag}_pmc.json"), "w"), indent=1)
-traffic["source"] = f"profiles/{tag}_pmc.json (2*FETCH_SIZE + WRITE_SIZE) KiB, B=4096 T=241 fp32"
+traffic["source"] = f"profiles/{tag}_pmc.json (2*FETCH_SIZE + WRITE_SIZE) KiB per launch"
+traffic["workloads"] = {"solve_*": "B=4096 T=241 fp32 (bench.py headline / train legs)",
+                        "fourgi_generate / win_*": "65 536 subjects x 61 grid points fp64, 196 608 windows 31/15 (bench.py data_side leg)"}
 sha_file = os.path.join(src, "kernel_source_sha.txt")
 traffic["kernel_source_sha"] = open(sha_file).read().strip() if os.path.exists(sha_file) else None
 json.dump(traffic, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
