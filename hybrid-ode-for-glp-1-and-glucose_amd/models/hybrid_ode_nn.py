@@ -78,7 +78,7 @@ def _tape_budget(dev):
     return max(1, min(TAPE_BUDGET_BYTES, int(0.8 * (free + reusable))))
 
 
-# Accepted-step budget of a solve that records a tape: every step costs 6*(L+1)*256 B of stage tape, so the default is
+# Accepted-step budget of a solve that records a tape: every step costs 6*(L*256 + 32) + 36 B of tape, so the default is
 # T-1 (one step per interval, what the benchmark regime takes) plus a margin.  `TAPE_STEP_MARGIN` / the `tape_steps`
 # attribute of a model change it; a trajectory that STILL needs more steps (stiff or z-scored data) is not lost: it is
 # integrated again with the no-grad budget in a second, small launch (_solve_taped), so a solve under autograd returns
@@ -100,7 +100,10 @@ def _eval_steps(T, method):
 
 class _Taped:
     """A forward solve with tape + the trajectories that ran out of tape steps and were integrated again with the
-    no-grad budget (`extras`: [(indices, set id, solve)]).  y / status / nsteps / nfev are the merged results."""
+    no-grad budget (`extras`: [(indices, set id, solve or None, args)]).  y / status / nsteps / nfev are the merged results.
+    An extra whose tape fitted the budget keeps it (solve != None); the others were integrated without a tape and are
+    re-integrated chunk by chunk in backward(), one tape buffer re-used -- the retries are bounded by the same budget as
+    everything else (4 096 retried trajectories at 12.6 MB each would otherwise ask for 51 GB on top of the tape)."""
 
     def __init__(self, sol, extras):
         self.sol, self.extras = sol, extras
@@ -109,34 +112,49 @@ class _Taped:
         if extras:
             # merged bookkeeping lives in COPIES: the adjoint of the main launch walks ITS tape with ITS step counts
             self.status, self.nsteps, self.nfev = sol.status.clone(), sol.nsteps.clone(), sol.nfev.clone()
-            for idx, _, s2 in extras:
+            for idx, _, s2, _ in extras:
                 self.y[idx], self.status[idx], self.nsteps[idx], self.nfev[idx] = s2.y, s2.status, s2.nsteps, s2.nfev
-        self.n_retried = sum(int(i.numel()) for i, _, _ in extras)
+        self.n_retried = sum(int(e[0].numel()) for e in extras)
 
     def backward(self, gy, want_gnn=True, want_gode=False):
         gy = gy.contiguous()
         subs = []
         if self.extras:
             gy = gy.clone()
-            for idx, _, _ in self.extras:
+            for idx, *_ in self.extras:
                 subs.append(gy[idx].contiguous())
                 gy[idx] = 0                     # the truncated copy in the main launch contributes nothing
         gx0, gnn, gode = hode.solve_bwd(self.sol, gy, want_gnn=want_gnn, want_gode=want_gode)
-        for (idx, set_id, sol2), g2 in zip(self.extras, subs):
-            g0, gn, go = hode.solve_bwd(sol2, g2, want_gnn=want_gnn, want_gode=want_gode)
-            gx0[idx] = g0
-            if gn is not None:
-                P = gn.numel()
-                gnn[P * set_id:P * (set_id + 1)] += gn
-            if go is not None:
-                gode[17 * set_id:17 * (set_id + 1)] += go
+        for (idx, set_id, sol2, lazy), g2 in zip(self.extras, subs):
+            if sol2.tape is not None:
+                g0, gn, go = hode.solve_bwd(sol2, g2, want_gnn=want_gnn, want_gode=want_gode)
+                self._add(gx0, gnn, gode, idx, set_id, g0, gn, go)
+                continue
+            solve, cap = lazy                    # re-integrate with a tape, `cap` trajectories at a time, one buffer
+            tape = None
+            for lo in range(0, idx.numel(), cap):
+                sl = slice(lo, min(lo + cap, idx.numel()))
+                sp = solve(sl, tape)
+                tape = sp.tape
+                g0, gn, go = hode.solve_bwd(sp, g2[sl].contiguous(), want_gnn=want_gnn, want_gode=want_gode)
+                self._add(gx0, gnn, gode, idx[sl], set_id, g0, gn, go)
         return gx0, gnn, gode
+
+    @staticmethod
+    def _add(gx0, gnn, gode, idx, set_id, g0, gn, go):
+        gx0[idx] = g0
+        if gn is not None:
+            P = gn.numel()
+            gnn[P * set_id:P * (set_id + 1)] += gn
+        if go is not None:
+            gode[17 * set_id:17 * (set_id + 1)] += go
 
 
 def _solve_taped(x0, t, meal, tvns, gd, ode_vec, nn_flat, H, L, method, rtol, atol, n_sets, steps, tape=None):
     """Forward solve with a tape of `steps` accepted steps per trajectory; status-1 trajectories (budget exhausted) are
     solved again, set by set, with the inference budget and their rows replace the truncated ones.  One host
-    synchronisation (the failure count); no second launch in the common case."""
+    synchronisation (the failure count); no second launch in the common case.  The retries' tapes count against the tape
+    budget: what does not fit is integrated without a tape now and re-integrated piecewise in the backward (_Taped)."""
     sol = hode.solve_fwd(x0, t, meal, tvns, gd, ode_vec, nn_flat, H, L, method=method, rtol=rtol, atol=atol, n_sets=n_sets,
                          want_tape=tape is None, tape=tape, max_steps=steps)
     extras = []
@@ -146,12 +164,26 @@ def _solve_taped(x0, t, meal, tvns, gd, ode_vec, nn_flat, H, L, method, rtol, at
         if bad.numel():
             per_set, P = x0.shape[0] // n_sets, nn_flat.numel() // n_sets
             cut = lambda v, i: None if v is None else v[i].contiguous()          # noqa: E731
+            per_traj = hode.capi.tape_nbytes(1, big, x0.element_size(), L, H)
+            left = _tape_budget(x0.device)
             for set_id in torch.unique(bad // per_set).tolist():
                 idx = bad[(bad // per_set) == set_id]
-                s2 = hode.solve_fwd(x0[idx].contiguous(), t[idx].contiguous() if t.dim() == 2 else t, cut(meal, idx), cut(tvns, idx),
-                                    cut(gd, idx), ode_vec[17 * set_id:17 * (set_id + 1)], nn_flat[P * set_id:P * (set_id + 1)], H, L,
-                                    method=method, rtol=rtol, atol=atol, n_sets=1, want_tape=True, max_steps=big)
-                extras.append((idx, set_id, s2))
+                xs, ts = x0[idx].contiguous(), (t[idx].contiguous() if t.dim() == 2 else t)
+                ms, vs, gs = cut(meal, idx), cut(tvns, idx), cut(gd, idx)
+                o1, n1 = ode_vec[17 * set_id:17 * (set_id + 1)], nn_flat[P * set_id:P * (set_id + 1)]
+
+                def solve(sl=None, tp=None, want=True, xs=xs, ts=ts, ms=ms, vs=vs, gs=gs, o1=o1, n1=n1):
+                    c2 = lambda v: None if v is None else (v if sl is None else v[sl].contiguous())   # noqa: E731
+                    return hode.solve_fwd(c2(xs), c2(ts) if ts.dim() == 2 else ts, c2(ms), c2(vs), c2(gs), o1, n1, H, L, method=method,
+                                          rtol=rtol, atol=atol, n_sets=1, want_tape=want and tp is None, tape=tp if want else None,
+                                          max_steps=big)
+                fits = idx.numel() * per_traj <= left
+                s2 = solve(want=fits)
+                if fits:
+                    left -= idx.numel() * per_traj
+                    extras.append((idx, set_id, s2, None))
+                else:
+                    extras.append((idx, set_id, s2, (solve, max(1, _tape_budget(x0.device) // (2 * per_traj)))))
     return _Taped(sol, extras)
 
 

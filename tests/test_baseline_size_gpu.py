@@ -1,0 +1,380 @@
+"""BASELINE.json configs 2, 3 and 5 at (or next to) their full size, checked against the ORACLE -- not against another run of
+the HIP path -- plus the failure statuses of the regime the reference's dataset really feeds (z-scored states,
+/root/reference/train/train_hybrid.py:139) and of its tests' stress states.  `-m gpu`; every call goes through the C ABI.
+
+The `test_cfg*` names sort these first in the suite (tests/conftest.py)."""
+import os
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+import bench  # noqa: E402  (the benchmark's own cohort / weight generators)
+from oracle import oracle as O  # noqa: E402  (checker only)
+
+H, L, T = 64, 4, 241
+NCPU = max(1, min(os.cpu_count() or 1, 16))
+
+
+def dev(a, dtype=torch.float32):
+    return None if a is None else torch.as_tensor(np.asarray(a), dtype=dtype, device="cuda")
+
+
+def relnorm(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-300))
+
+
+def oracle_fwd_bwd(x0, t, meal, tvns, ode, nn, cot, rtol=1e-10, atol=1e-12, dtype=np.float64, chunk=4, max_steps=None):
+    """fp64 oracle solve + adjoint over chunks of trajectories on all host cores (ctypes releases the GIL).
+    cot(y_chunk, lo, hi) -> dLoss/dy of that chunk.  Returns y, status, gx0, gnn (summed), gode (summed)."""
+    B = x0.shape[0]
+
+    def work(lo):
+        hi = min(lo + chunk, B)
+        s = O.solve(x0[lo:hi], t if t.ndim == 1 else t[lo:hi], meal[lo:hi], tvns[lo:hi], None, ode, nn, H, L, rtol=rtol, atol=atol,
+                    dtype=dtype, want_tape=True, max_steps=max_steps)
+        gx, gn, go = O.solve_bwd(s, cot(s.y, lo, hi))
+        return lo, hi, s.y, s.status, s.nsteps, gx, gn, go
+    with ThreadPoolExecutor(NCPU) as ex:
+        parts = list(ex.map(work, range(0, B, chunk)))
+    y = np.concatenate([p[2] for p in parts])
+    st = np.concatenate([p[3] for p in parts])
+    ns = np.concatenate([p[4] for p in parts])
+    gx = np.concatenate([p[5] for p in parts])
+    return y, st, ns, gx, sum(p[6] for p in parts), sum(p[7] for p in parts)
+
+
+@pytest.fixture(scope="module")
+def hode():
+    import hode as h
+    h.load()
+    return h
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# failure statuses
+def _failure_cohort():
+    """256 patients of bench.py's z-scored cohort (x0 ~ N(0,1)^6, seed 4242, the benchmark's meals) + the reference's stress states
+    (tests/test_ode_jacobians.py:173-206 `extreme_states`; tests/test_gradient_correctness.py:211-256 x0 = 10 randn, meals up to
+    50, tVNS = 1) + states that cannot be integrated at all: NaN / Inf in x0, a NaN in the meal row half way, an fp32 overflow."""
+    _, t, meal, tvns = (v.numpy().astype(np.float64) for v in bench.synth_cohort(4096, 1000))
+    xz = torch.randn(4096, 6, generator=torch.Generator().manual_seed(4242)).numpy().astype(np.float64)[:256]
+    mz, vz = meal[:256].copy(), tvns[:256].copy()
+    g = torch.Generator().manual_seed(5)
+    ext = np.array([[20.0, 500.0, 200.0, 100.0, 2.0, 5.0], [2.0, 10.0, 10.0, 5.0, 0.0, 0.1], [5.0, 100.0, 50.0, 20.0, 0.0, 1.0]])
+    xs = np.concatenate([ext, (torch.randn(29, 6, generator=g) * 10).numpy().astype(np.float64)])
+    ms = np.zeros((32, T))
+    ms[:, ::4] = (torch.rand(32, 61, generator=g) * 50).numpy()            # large meal inputs on every fourth grid point
+    vs = np.ones((32, T))
+    base = np.array([5.0, 60.0, 80.0, 10.0, 0.0, 1.0])
+    xb = np.tile(base, (8, 1))
+    mb, vb = np.zeros((8, T)), np.zeros((8, T))
+    xb[0, 2] = np.nan                    # missing value in the initial state
+    xb[1, 0] = np.inf
+    mb[2, 100] = np.nan                  # missing value in an input row: fails in interval 99, rows 0..99 are good
+    xb[3, 5] = 3.0e38                    # FFA at the edge of fp32: (-p7 - p8 I + p9 G) F overflows in the first stage combination
+    mb[4, 7] = 1.0                       # healthy neighbours in the same launch
+    x0 = np.concatenate([xz, xs, xb])
+    return x0, t, np.concatenate([mz, ms, mb]), np.concatenate([vz, vs, vb])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_cfg2_failure_statuses_rows_and_adjoint_match_oracle(hode, dtype):
+    """Reference behaviour on a failed integration (models/hybrid_ode_nn.py:243-256): warn, keep the rows computed so far, zeros
+    beyond.  Here: per-trajectory status 2 (step size underflow: the pole of G/(K_m+G) or GLP1/(EC_50+GLP1) is reached in finite
+    time -- what SciPy reports as 'Required step size is less than spacing between numbers') and 3 (non-finite state) must BOTH
+    occur and equal the oracle's, trajectory by trajectory; nsteps within 1; rows written before the failure agree; rows after
+    it are exactly zero; and the ADJOINT of such a batch equals the oracle's adjoint (failed trajectories contribute the
+    cotangents of the rows they wrote, nothing else; healthy neighbours are untouched; nothing non-finite leaks into the
+    shared parameter gradient)."""
+    npd = np.float32 if dtype == torch.float32 else np.float64
+    x0, t, meal, tvns = _failure_cohort()
+    B = x0.shape[0]
+    nn, ode = bench.synth_weights(0).numpy().astype(np.float64), bench.ODE_DEFAULT.numpy().astype(np.float64)
+    max_steps = 8 * (T - 1) + 64
+    rng = np.random.default_rng(11)
+    c = rng.standard_normal((B, T, 6)) / (B * T * 6)
+    c[B - 8, 3, :] = np.nan                 # a cotangent on a row that was never written (failed at row 0) must be ignored ...
+    c[B - 6, 150, :] = np.inf               # ... also far behind the failure (NaN meal at grid index 100)
+    with np.errstate(all="ignore"):
+        yo, sto, nso, gxo, gno, goo = oracle_fwd_bwd(x0.astype(npd), t.astype(npd), meal.astype(npd), tvns.astype(npd), ode, nn,
+                                                    lambda y, lo, hi: c[lo:hi].astype(npd), rtol=1e-6, atol=1e-8, dtype=npd,
+                                                    max_steps=max_steps)
+    assert (sto == 2).sum() >= 3 and (sto == 3).sum() >= 3 and (sto == 0).sum() >= 250, np.bincount(sto, minlength=4)
+    s = hode.solve_fwd(dev(x0, dtype), dev(t, dtype), dev(meal, dtype), dev(tvns, dtype), None, dev(ode, dtype), dev(nn, dtype), H, L,
+                       rtol=1e-6, atol=1e-8, want_tape=True, max_steps=max_steps)
+    st, ns, y = s.status.cpu().numpy(), s.nsteps.cpu().numpy(), s.y.cpu().numpy().astype(np.float64)
+    assert np.array_equal(st, sto), (np.nonzero(st != sto)[0], st[st != sto], sto[st != sto])
+    ok = sto == 0
+    # a trajectory that dies on a pole takes ever smaller steps: the last accepted ones are a matter of the last bit
+    assert np.abs(ns[ok] - nso[ok]).max() <= 1 and np.abs(ns[~ok] - nso[~ok]).max() <= 3, np.abs(ns - nso).max()
+    tol = 2e-5 if dtype == torch.float32 else 1e-8
+    for b in range(B):
+        written_o = np.nonzero(np.any(yo[b] != 0, axis=1))[0]
+        kz_o = written_o.max() + 1 if written_o.size else 0                 # first row the oracle left at zero
+        written = np.nonzero(np.any(y[b] != 0, axis=1))[0]
+        kz = written.max() + 1 if written.size else 0
+        if ok[b]:
+            assert kz == T and kz_o == T
+            err = np.max(np.abs(y[b] - yo[b]) / (np.abs(yo[b]) + 1e-3))
+            assert err < tol, (b, err)
+        else:
+            assert kz == kz_o, (b, int(st[b]), kz, kz_o)                    # fails in the same grid interval
+            assert np.all(y[b, kz:] == 0.0) and np.all(np.isfinite(y[b]))  # rows after the failure: exactly zero
+            if kz > 3:
+                # rows written before the failure; the rows next to a pole are ill-conditioned (dx/dt ~ 1/(K_m+G)): the bar holds
+                # up to three rows before the end
+                err = np.max(np.abs(y[b, :kz - 3] - yo[b, :kz - 3]) / (np.abs(yo[b, :kz - 3]) + 1e-3))
+                assert err < 50 * tol, (b, int(st[b]), kz, err)
+    # ---- adjoint of the same batch
+    gx0, gnn, gode = hode.solve_bwd(s, dev(c, dtype), want_gode=True)
+    gx0, gnn, gode = gx0.cpu().numpy(), gnn.cpu().numpy(), gode.cpu().numpy()
+    assert np.all(np.isfinite(gnn)) and np.all(np.isfinite(gode)) and np.all(np.isfinite(gno)) and np.all(np.isfinite(goo))
+    assert np.all(np.isfinite(gx0[ok])) and np.all(np.isfinite(gx0[sto == 2]))
+    gtol = 2e-4 if dtype == torch.float32 else 1e-7
+    assert relnorm(gx0[ok], gxo[ok]) < gtol
+    # trajectories that failed at row 0 wrote nothing but row 0 itself: gx0 = the cotangent of row 0
+    dead = np.array([B - 8, B - 7])
+    assert np.allclose(gx0[dead], c[dead, 0, :], rtol=1e-6, atol=0) and np.allclose(gxo[dead], c[dead, 0, :], rtol=1e-6, atol=0)
+    # status-2 trajectories: the adjoint walks up to the pole; compare trajectory by trajectory, relative to each one's own size
+    for b in np.nonzero(sto == 2)[0]:
+        assert relnorm(gx0[b], gxo[b]) < (5e-2 if dtype == torch.float32 else 1e-4), (b, gx0[b], gxo[b])
+    # the shared parameter gradient: dominated by whatever the near-pole steps contribute, still the same vector
+    assert relnorm(gnn, gno) < (5e-2 if dtype == torch.float32 else 1e-4), relnorm(gnn, gno)
+    assert relnorm(gode, goo) < (5e-2 if dtype == torch.float32 else 1e-4), relnorm(gode, goo)
+    # ... and with the ill-conditioned trajectories' cotangents zeroed the usual bars hold for the whole batch (the failed ones
+    # still walk their tapes, with zero cotangents: nothing non-finite may leak out of them)
+    c2 = c.copy()
+    c2[~ok] = 0.0
+    with np.errstate(all="ignore"):
+        _, _, _, gxo2, gno2, goo2 = oracle_fwd_bwd(x0.astype(npd), t.astype(npd), meal.astype(npd), tvns.astype(npd), ode, nn,
+                                                   lambda y_, lo, hi: c2[lo:hi].astype(npd), rtol=1e-6, atol=1e-8, dtype=npd,
+                                                   max_steps=max_steps)
+    gx2, gnn2, gode2 = (v.cpu().numpy() for v in hode.solve_bwd(s, dev(c2, dtype), want_gode=True))
+    assert relnorm(gnn2, gno2) < gtol and relnorm(gode2, goo2) < 10 * gtol and relnorm(gx2[ok], gxo2[ok]) < gtol
+    assert np.all(gx2[~ok] == 0.0)
+
+
+def test_rk4_blow_up_is_status_3_and_never_reaches_the_tape(hode):
+    """a fixed-step RK4 step whose result is not finite is not an accepted step -- it is not on the tape, its row is
+    not written, and the adjoint of the batch stays finite (the shared gnn / gode must not be poisoned by one patient)."""
+    Tn = 21
+    t = np.linspace(0.0, 20.0, Tn)                    # one-hour RK4 steps
+    base = np.array([5.0, 60.0, 80.0, 10.0, 0.0, 1.0])
+    x0 = np.tile(base, (6, 1))
+    x0[1, 5] = 1.0e30                                 # FFA: (p9 G - p7 - p8 I) F with h = 1 overflows fp32 after a few steps
+    x0[4, 1] = 3.0e38
+    meal = np.zeros((6, Tn))
+    meal[:, 3] = 1.0
+    tv = np.zeros((6, Tn))
+    nn, ode = bench.synth_weights(0).numpy(), bench.ODE_DEFAULT.numpy()
+    with np.errstate(all="ignore"):
+        ref = O.solve(x0, t, meal, tv, None, ode, nn, H, L, method=O.METHOD_RK4, dtype=np.float32, want_tape=True, max_steps=Tn - 1)
+    assert (ref.status == 3).sum() >= 1 and (ref.status == 0).sum() >= 4, ref.status
+    s = hode.solve_fwd(dev(x0), dev(t), dev(meal), dev(tv), None, dev(ode), dev(nn), H, L, method=hode.METHOD_RK4, want_tape=True,
+                       max_steps=Tn - 1)
+    assert np.array_equal(s.status.cpu().numpy(), ref.status) and np.array_equal(s.nsteps.cpu().numpy(), ref.nsteps)
+    y = s.y.cpu().numpy()
+    assert np.all(np.isfinite(y))
+    for b in np.nonzero(ref.status == 3)[0]:
+        k = int(ref.nsteps[b])                        # rows 0..k were written, the rest is zero
+        assert np.all(y[b, k + 1:] == 0) and np.all(ref.y[b, k + 1:] == 0)
+    c = np.random.default_rng(2).standard_normal(y.shape).astype(np.float32)
+    gx0, gnn, gode = hode.solve_bwd(s, dev(c), want_gode=True)
+    with np.errstate(all="ignore"):
+        rx, rnn, rode = O.solve_bwd(ref, c)
+    assert torch.isfinite(gnn).all() and torch.isfinite(gode).all() and np.all(np.isfinite(rnn))
+    okb = ref.status == 0
+    assert relnorm(gx0.cpu().numpy()[okb], rx[okb]) < 1e-4
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# BASELINE config 3 at its size, against the oracle
+def test_cfg3_train_step_4096x241_gradients_vs_fp64_oracle_then_adam(hode):
+    """One fused training step of BASELINE config 3 -- 4 096 patients x 241 grid points: forward with tape, fused MSE +
+    cotangent, adjoint, clip + Adam.  The gradients of THIS launch are compared with the fp64 oracle at converged tolerances:
+    gx0 of 32 patients sampled over the whole batch, and the parameter gradient through a 64-patient sub-batch run with the
+    same global cotangent scale (the full-batch gradient is its sum with the rest's, checked at 1e-5).  Then the update against
+    clip_grad_norm_ + torch.optim.Adam."""
+    B = 4096
+    x0, t, meal, tvns = bench.synth_cohort(B, 1000)
+    nn_t, ode = bench.synth_weights(0), bench.ODE_DEFAULT
+    d = torch.device("cuda")
+    obs, student = bench.train_problem(d, x0.to(d), t.to(d), meal.to(d), tvns.to(d), ode.to(d), nn_t.to(d), 0)
+    n_glob = B * T * 6
+    xd, td, md, vd, od = x0.to(d), t.to(d), meal.to(d), tvns.to(d), ode.to(d)
+
+    def step(lo, hi):
+        sol = hode.solve_fwd(xd[lo:hi].contiguous(), td, md[lo:hi].contiguous(), vd[lo:hi].contiguous(), None, od, student, H, L, want_tape=True)
+        ls, gy = hode.mse_fwd_bwd(sol.y, obs[lo:hi].contiguous(), 1.0 / n_glob)
+        gx0, gnn, _ = hode.solve_bwd(sol, gy)
+        return sol, float(ls), gx0, gnn
+    sol, ls, gx0, gnn = step(0, B)
+    assert int(sol.status.max()) == 0
+    _, ls_a, gx_a, gnn_a = step(0, 64)
+    _, ls_b, gx_b, gnn_b = step(64, B)
+    assert relnorm((gnn_a + gnn_b).cpu().numpy(), gnn.cpu().numpy()) < 1e-5 and abs(ls_a + ls_b - ls) < 1e-9 * ls
+    assert torch.equal(gx0[:64], gx_a)                                    # a trajectory's gx0 does not depend on its batch
+    # oracle: the 64-patient sub-batch + 32 patients sampled from the rest
+    idx = np.concatenate([np.arange(64), 64 + np.sort(np.random.default_rng(3).choice(B - 64, 32, replace=False))])
+    obs_h = obs.cpu().numpy().astype(np.float64)
+    p64, ode64 = student.cpu().numpy().astype(np.float64), ode.numpy().astype(np.float64)
+    yo, sto, _, gxo, _, _ = oracle_fwd_bwd(x0.numpy()[idx].astype(np.float64), t.numpy().astype(np.float64), meal.numpy()[idx].astype(np.float64),
+                                           tvns.numpy()[idx].astype(np.float64), ode64, p64,
+                                           lambda y, lo, hi: 2.0 * (y - obs_h[idx[lo:hi]]) / n_glob)
+    assert int(sto.max()) == 0
+    yk = sol.y.cpu().numpy()[idx]
+    assert float(np.max(np.abs(yk - yo) / (np.abs(yo) + 1e-3))) < 1e-4          # forward rows of the same 96 patients
+    gxk = gx0.cpu().numpy()[idx]
+    for j in range(len(idx)):
+        assert relnorm(gxk[j], gxo[j]) < 1e-4, (int(idx[j]), relnorm(gxk[j], gxo[j]))
+    _, _, _, _, gno, _ = oracle_fwd_bwd(x0.numpy()[:64].astype(np.float64), t.numpy().astype(np.float64), meal.numpy()[:64].astype(np.float64),
+                                        tvns.numpy()[:64].astype(np.float64), ode64, p64,
+                                        lambda y, lo, hi: 2.0 * (y - obs_h[lo:hi]) / n_glob)
+    assert relnorm(gnn_a.cpu().numpy(), gno) < 1e-4, relnorm(gnn_a.cpu().numpy(), gno)
+    # the update: fused clip + Adam kernel vs torch on the full-batch gradient
+    p_t = torch.nn.Parameter(student.clone())
+    p_t.grad = gnn.clone()
+    opt = torch.optim.Adam([p_t], lr=1e-3)
+    torch.nn.utils.clip_grad_norm_([p_t], 5.0)
+    opt.step()
+    p_k, m, v = student.clone(), torch.zeros_like(student), torch.zeros_like(student)
+    hode.adam_step(p_k, gnn, m, v, 1e-3, step=1, max_norm=5.0)
+    assert float((p_k - p_t.detach()).abs().max()) < 2e-6 and float((p_k - student).abs().max()) > 1e-5
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# BASELINE config 5 with the real network against the oracle
+def _vi_model(M):
+    prior = {f"ode_{n}": {"mean": v, "std": 0.02 * v} for n, v in
+             [("a_GI", 0.0104), ("k_I", 0.025), ("rho", 0.003), ("E_max", 0.1), ("EC_50", 50.0), ("V_max", 9.0), ("K_m", 7.0), ("k_L", 0.02)]}
+    torch.manual_seed(0)
+    m = M.HybridODENN(use_variational=True, prior_params=prior, device="cuda")          # the 4 x 64 network
+    teacher = bench.synth_weights(0)
+    with torch.no_grad():
+        off = 0
+        for name, p in m.nn_residual.named_parameters():
+            m.variational_params.means["nn_" + name.replace(".", "_")].copy_(teacher[off:off + p.numel()].reshape(p.shape))
+            off += p.numel()
+        for n, p in m.variational_params.log_stds.items():
+            p.fill_(-5.0 if n.startswith("nn_") else float(np.log(0.02 * prior[n]["mean"])))
+    return m, prior
+
+
+def test_cfg5_elbo_4x64_16_draws_value_and_gradient_vs_per_draw_oracle(monkeypatch):
+    """BASELINE config 5's arithmetic with the REAL network (4 x 64), S = 16 draws x B = 8 patients, T = 61: `elbo()` (one
+    launch for all draws, fp64 KL and likelihood, reparameterised gradient through the adjoint) against per-draw fp64 oracle
+    solves at converged tolerances: value to 1e-5, d ELBO / d mu of every MLP weight and ODE constant against the oracle's
+    adjoint (theta = mu + eps sigma: d theta / d mu = 1, d theta / d log sigma = eps sigma) to 1e-4.  Then the same ELBO
+    through the chunked route (tape budget squeezed to two draws per piece): same value, same gradient."""
+    import models as M
+    import models.hybrid_ode_nn as MH
+    m, prior = _vi_model(M)
+    S, B, Tn, sigma = 16, 8, 61, 1.0
+    x0, t, meal, tvns = bench.synth_cohort(64, 555)
+    x0, meal, tvns, t = x0[:B], meal[:B, :Tn].contiguous(), tvns[:B, :Tn].contiguous(), t[:Tn].contiguous()
+    with torch.no_grad():
+        y_mean = m.forward_with_params({k: v.detach() for k, v in m.variational_params.means.items()}, x0.cuda(), t.cuda(),
+                                       {"meal": meal.cuda(), "tVNS": tvns.cuda()})
+    obs = y_mean + sigma * torch.randn(y_mean.shape, device="cuda", generator=torch.Generator("cuda").manual_seed(9))
+    batch = {"initial_state": x0.cuda(), "observations": obs, "time_points": t.cuda(), "external_inputs": {"meal": meal.cuda(), "tVNS": tvns.cuda()}}
+    vp = m.variational_params
+
+    def run():
+        m.zero_grad()
+        torch.manual_seed(21)
+        e, comp = m.elbo(batch, n_samples=S, noise_sigma=sigma, return_components=True)
+        e.backward()
+        return float(e), float(comp["log_likelihood"]), float(comp["kl"]), {n: p.grad.detach().cpu().double().numpy().copy() for n, p in vp.means.items()}, \
+            {n: p.grad.detach().cpu().double().numpy().copy() for n, p in vp.log_stds.items()}
+    e, ll, kl, gmu, gls = run()
+    assert int((m.last_solve_info["status"] != 0).sum()) == 0 and m.last_solve_info["status"].numel() == S * B
+    # the same draws, one oracle solve + adjoint per draw
+    torch.manual_seed(21)
+    draws = vp.sample(S)
+    obs_h = obs.cpu().numpy().astype(np.float64)
+    xs, ts, ms, vs = (v.numpy().astype(np.float64) for v in (x0, t, meal, tvns))
+    ll_o, gmu_o, gls_o = 0.0, {n: np.zeros(p.shape) for n, p in vp.means.items()}, {n: np.zeros(p.shape) for n, p in vp.means.items()}
+    names_nn = ["nn_" + n.replace(".", "_") for n, _ in m.nn_residual.named_parameters()]
+    from models.ode_core import ODE_PARAM_NAMES
+    for d in draws:
+        nn_flat, ode_vec = m._params_on(torch.device("cuda"), d)
+        nn64, ode64 = nn_flat.detach().cpu().double().numpy(), ode_vec.detach().cpu().double().numpy()
+        yo, sto, _, _, gn, go = oracle_fwd_bwd(xs, ts, ms, vs, ode64, nn64, lambda y, lo, hi: -(y - obs_h[lo:hi]) / (sigma ** 2 * S))
+        assert int(sto.max()) == 0
+        ll_o += -0.5 * float(((yo - obs_h) ** 2).sum()) / (sigma ** 2 * S)
+        off = 0
+        for n in names_nn:
+            k = int(np.prod(vp.means[n].shape))
+            g = gn[off:off + k].reshape(tuple(vp.means[n].shape))
+            off += k
+            eps_sig = (d[n] - vp.means[n]).detach().cpu().double().numpy()          # eps * sigma of this draw
+            gmu_o[n] += g
+            gls_o[n] += g * eps_sig
+        for i, n in enumerate(ODE_PARAM_NAMES):
+            key = "ode_" + n
+            if key in gmu_o:
+                eps_sig = (d[key] - vp.means[key]).detach().cpu().double().numpy()
+                gmu_o[key] += go[i]
+                gls_o[key] += go[i] * eps_sig
+    ll_o -= 0.5 * obs_h.size * np.log(2 * np.pi * sigma ** 2)
+    kl_o = 0.0
+    for n in vp.param_shapes:
+        mu, ls = vp.means[n].detach().cpu().double().numpy(), vp.log_stds[n].detach().cpu().double().numpy()
+        mu_p, s_p = vp.prior_means.get(n, 0.0), vp.prior_stds.get(n, 1.0)
+        kl_o += float((np.log(s_p) - ls + (np.exp(2 * ls) + (mu - mu_p) ** 2) / (2 * s_p ** 2) - 0.5).sum())
+        gmu_o[n] -= (mu - mu_p) / s_p ** 2
+        gls_o[n] -= (-1.0 + np.exp(2 * ls) / s_p ** 2)
+    assert abs(kl - kl_o) < 1e-6 * abs(kl_o)
+    assert abs(ll - ll_o) < 1e-5 * abs(ll_o), (ll, ll_o)
+    assert abs(e - (ll_o - kl_o)) < 1e-5 * abs(ll_o - kl_o)
+    flat = lambda dct, keys: np.concatenate([np.asarray(dct[k]).reshape(-1) for k in keys])           # noqa: E731
+    ode_keys = [k for k in vp.param_shapes if k.startswith("ode_")]
+    assert relnorm(flat(gmu, names_nn), flat(gmu_o, names_nn)) < 1e-4, relnorm(flat(gmu, names_nn), flat(gmu_o, names_nn))
+    assert relnorm(flat(gls, names_nn), flat(gls_o, names_nn)) < 1e-4
+    for k in ode_keys:                          # eight scalars of very different size: one by one
+        assert abs(float(gmu[k]) - float(gmu_o[k])) < 2e-4 * abs(float(gmu_o[k])) + 1e-9, (k, float(gmu[k]), float(gmu_o[k]))
+    # three individual weights, as the reference's FD spot checks pick them
+    for name, ix in [("nn_network_0_weight", (3, 2)), ("nn_network_4_weight", (10, 20)), ("nn_network_8_weight", (1, 7))]:
+        a, b = float(gmu[name][ix]), float(gmu_o[name][ix])
+        assert abs(a - b) < 1e-4 * abs(b) + 1e-7 * float(np.abs(gmu_o[name]).max()), (name, a, b)
+    # ---- the chunked route: the tape budget admits two draws (16 trajectories) per piece
+    per_traj = __import__("hode").capi.tape_nbytes(1, MH._tape_steps(Tn, 0, None), 4, L, H)
+    monkeypatch.setattr(MH, "_tape_budget", lambda dev_: 2 * B * per_traj + 1)
+    assert len(MH._pieces(S, B, 2 * B)) == 8
+    e2, ll2, kl2, gmu2, gls2 = run()
+    assert abs(e2 - e) < 1e-9 * abs(e) and kl2 == kl
+    assert relnorm(flat(gmu2, names_nn), flat(gmu, names_nn)) < 1e-5 and relnorm(flat(gls2, names_nn), flat(gls, names_nn)) < 1e-5
+    # ... and slices of one draw (budget below one draw's 8 trajectories)
+    monkeypatch.setattr(MH, "_tape_budget", lambda dev_: 3 * per_traj + 1)
+    e3, _, _, gmu3, _ = run()
+    assert abs(e3 - e) < 1e-9 * abs(e) and relnorm(flat(gmu3, names_nn), flat(gmu, names_nn)) < 1e-5
+
+
+def test_cfg5_posterior_predictive_module_function_equals_the_vi_method():
+    """reference models/bayes.py:177-214 `compute_posterior_predictive(model, x_initial, t_span, external_inputs, n_samples)` and
+    inference/vi.py:273-312 `VariationalInference.posterior_predictive` draw `sample(1)` n_samples times and reduce over the
+    draws: under the same seed they are the same numbers (one launch each here), and equal the draws integrated one at a time."""
+    import models as M
+    from inference.vi import VariationalInference
+    m, _ = _vi_model(M)
+    x0, t, meal, tvns = bench.synth_cohort(8, 31)
+    x0, t, ext = x0[:3].cuda(), t[:31].contiguous().cuda(), {"meal": meal[:3, :31].contiguous().cuda(), "tVNS": tvns[:3, :31].contiguous().cuda()}
+    torch.manual_seed(5)
+    mean_a, std_a = M.compute_posterior_predictive(m, x0, t, ext, n_samples=6)
+    vi = VariationalInference(m, device=torch.device("cuda"))
+    torch.manual_seed(5)
+    mean_b, std_b = vi.posterior_predictive(x0, t, ext, n_samples=6)
+    assert tuple(mean_a.shape) == (3, 31, 6) and torch.equal(mean_a, mean_b) and torch.equal(std_a, std_b)
+    torch.manual_seed(5)
+    with torch.no_grad():
+        ys = torch.stack([m.forward_with_params(m.sample_posterior(1)[0], x0, t, ext) for _ in range(6)])
+    assert torch.equal(ys.mean(0), mean_a) and torch.equal(ys.std(0), std_a) and float(std_a.max()) > 0
+    # single patient: (n_time, n_states), as the reference documents
+    torch.manual_seed(5)
+    m1, s1 = M.compute_posterior_predictive(m, x0[0], t, {k: v[0] for k, v in ext.items()}, n_samples=4)
+    assert tuple(m1.shape) == (31, 6) and tuple(s1.shape) == (31, 6)

@@ -183,6 +183,50 @@ def test_loss_vs_reference_golden(M, golden_dir, fname, lam1, lam2):
     assert relnorm(grads, g["grads"]) < 5e-3
 
 
+@pytest.mark.parametrize("fname", ["g5t_loss_b2_t5.npz", "g5t_loss_b3_t10_shared.npz", "g5t_loss_b4_t25_shared.npz"])
+def test_loss_vs_reference_at_converged_tolerances(M, golden_dir, fname):
+    """G5-tight: the reference's loss() with its `forward` defaults overridden in the capture process to solver='rk45',
+    rtol=1e-10, atol=1e-12 (tools/capture_golden.py:g5_tight), i.e. the loss of the CONVERGED trajectories -- which is what this
+    path computes at its default tolerances.  Unlike the default-tolerance G5 above (DOP853 at 1e-6, itself ~1e-2 off) this
+    fixture can see a wrong m / n factor or a mis-weighted term: total and data to 1e-5, the PHYSICS component on its own and
+    each of its per-index terms, the L2 term, and the gradients.  b4_t25: T = 25 > 20 sampled indices."""
+    g = np.load(os.path.join(golden_dir, fname))
+    lam1, lam2 = float(g["lambda1"]), float(g["lambda2"])
+    m = M.HybridODENN(nn_hidden=32, nn_layers=2, device="cuda")
+    flat = torch.tensor(g["nn_flat"])
+    off = 0
+    with torch.no_grad():
+        for p in m.nn_residual.parameters():
+            p.copy_(flat[off:off + p.numel()].reshape(p.shape))
+            off += p.numel()
+    m.adjoint = False                     # the reference's solve is detached (SURVEY F3): gradients = physics term + L2
+    batch = {"initial_state": torch.tensor(g["x0"]), "observations": torch.tensor(g["obs"]), "time_points": torch.tensor(g["t"]),
+             "external_inputs": {"meal": torch.tensor(g["meal"]), "tVNS": torch.tensor(g["tvns"])}}
+    perm = torch.tensor(g["perm"])
+    orig = torch.randperm
+    torch.randperm = lambda n, *a, **k: perm.clone()
+    try:
+        loss = m.loss(batch, lambda1=lam1, lambda2=lam2)
+    finally:
+        torch.randperm = orig
+    assert m.solve_failures() == 0
+    data, phys, reg = (float(v) for v in m.last_loss_components)
+    assert abs(data - float(g["data"])) < 1e-5 * abs(float(g["data"])), (data, float(g["data"]))
+    assert abs(reg - float(g["reg"])) < 1e-6 * abs(float(g["reg"]))
+    # (x(0.1) - x) / 0.1 - f is a difference of nearly equal fp32 numbers in the reference and here: 1e-3 is what the
+    # component itself supports; a wrong m / n or a dropped index would be an error of 5-50 %
+    assert abs(phys - float(g["physics"])) < 1e-3 * abs(float(g["physics"])), (phys, float(g["physics"]))
+    assert abs(float(loss.detach()) - float(g["total"])) < 1e-5 * abs(float(g["total"]))
+    assert abs(data + lam1 * phys + lam2 * reg - float(loss.detach())) < 1e-6 * abs(float(loss.detach()))
+    loss.backward()
+    grads = torch.cat([p.grad.reshape(-1) for p in m.nn_residual.parameters()]).cpu().numpy()
+    assert relnorm(grads, g["grads"]) < 1e-4, relnorm(grads, g["grads"])
+    # trajectories themselves
+    with torch.no_grad():
+        pred = m.forward(batch["initial_state"], batch["time_points"], batch["external_inputs"])
+    assert rel(pred.cpu().numpy(), g["pred_rk45_tight"].astype(np.float64)) < 1e-4
+
+
 def test_adjoint_gradient_through_class(M, golden_dir):
     """loss.backward() with adjoint=True: d(data MSE)/d(MLP weights) == oracle adjoint (1e-4 bar)."""
     g = np.load(os.path.join(golden_dir, "g4_t61_rand.npz"))
@@ -260,6 +304,33 @@ def test_trajectories_that_outrun_the_tape_budget_are_retried_not_lost(M, golden
         # fp32 steps at a tolerance below fp32 resolution against the fp64 oracle: 3e-4 measured; a gradient that stopped at the
         # 14-step budget would be off by O(1)
         assert relnorm(gr, scale * rnn) < 1e-3, fused
+
+
+def test_retried_trajectories_whose_tapes_exceed_the_budget_are_reintegrated_piecewise(M, golden_dir, monkeypatch):
+    """the retry tapes (no-grad step budget: 12.6 MB per trajectory at T = 241) count against the tape budget.  With a
+    budget that holds the main tape but only two and a half retry tapes, the five retried trajectories are integrated without
+    a tape in the forward and re-integrated one at a time in the backward: same values, same gradient as the unconstrained run."""
+    import hode
+    import models.hybrid_ode_nn as MH
+    g = np.load(os.path.join(golden_dir, "g4_t61_pulses.npz"))
+    sel = np.arange(0, 61, 6)
+    x0, t = torch.tensor(g["x0"][:5]).cuda(), torch.tensor(g["t"][sel]).cuda()
+    u = {"meal": torch.tensor(g["meal"][:5, sel]).cuda(), "tVNS": torch.tensor(g["tvns"][:5, sel]).cuda()}
+    res = []
+    for squeeze in (False, True):
+        m = load_model(M, golden_dir, "cuda")
+        m.fused_likelihood = False
+        m.tape_steps = 14
+        if squeeze:
+            big = hode.capi.tape_nbytes(1, MH._eval_steps(11, hode.METHOD_DP54), 4, 4, 64)
+            monkeypatch.setattr(MH, "_tape_budget", lambda dev_: int(2.5 * big))
+        y = m.forward(x0, t, u, rtol=1e-9, atol=1e-11)
+        assert m.solve_failures() == 0 and m.last_solve_info["n_budget_retries"] == 5
+        c = torch.randn(y.shape, device="cuda", generator=torch.Generator("cuda").manual_seed(8))
+        (y * c).sum().backward()
+        res.append((y.detach().clone(), torch.cat([p.grad.reshape(-1) for p in m.nn_residual.parameters()]).clone()))
+    assert torch.equal(res[0][0], res[1][0])
+    assert relnorm(res[1][1].cpu().numpy(), res[0][1].cpu().numpy()) < 1e-5
 
 
 def test_validation_under_no_grad_and_ablations(M):
