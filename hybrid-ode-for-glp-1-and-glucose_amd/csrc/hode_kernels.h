@@ -28,6 +28,8 @@ template <typename R> struct AdjArgs {
     const R *gy;
     R *gx0, *gnn, *gode;
     R *tape_delta;      // fp32 tuned shapes: [B][max_steps][6][delta_slot_elems] scratch of the split adjoint (part of the tape)
+    R *partials;        // tuned shapes: [adj_partial_rows(B)][adj_partial_rowlen(P)] per-workgroup gradient sums (tail of the tape)
+    int partial_rows;
 };
 
 template <typename R> struct RhsArgs {
@@ -125,10 +127,26 @@ inline size_t tape_delta_offset(int B, int max_steps, size_t elem, int H, int L)
     size_t o = tape_stage_offset(B, max_steps, elem) + (size_t)B * max_steps * 6 * tape_slot_elems(H, L) * elem;
     return (o + 255) & ~(size_t)255;
 }
+// Gradient partials of the tuned adjoint: every workgroup writes ONE row [ dL/d nn_p (P) | dL/d ode_p (17) | pad ] and a second,
+// fixed-order pass adds the rows into gnn / gode -- no floating-point atomics, so a training step is bit-reproducible run to
+// run (the reference's CPU training is deterministic; fp32 atomics from 256 workgroups are not).  The rows live in the tail of
+// the tape, the adjoint's workspace (nothing is allocated inside the library): at most kAdjPartialRows of them, never more
+// than there are trajectories (a launch has at most one workgroup per trajectory).
+constexpr int kAdjPartialRows = 1024;
+__host__ __device__ inline int adj_partial_rows(int B) { return B < kAdjPartialRows ? B : kAdjPartialRows; }
+__host__ __device__ inline size_t adj_partial_rowlen(int P) { return (size_t)(P + 17 + 63) / 64 * 64; }
+inline size_t tape_partials_offset(int B, int max_steps, size_t elem, int H, int L)
+{
+    size_t o = tape_delta_offset(B, max_steps, elem, H, L);
+    if (has_delta_tape(elem, H, L)) o += (size_t)B * max_steps * 6 * delta_slot_elems(L) * elem;
+    return (o + 255) & ~(size_t)255;
+}
 inline size_t tape_total_bytes(int B, int max_steps, size_t elem, int H, int L)
 {
-    const size_t o = tape_delta_offset(B, max_steps, elem, H, L);
-    return has_delta_tape(elem, H, L) ? o + (size_t)B * max_steps * 6 * delta_slot_elems(L) * elem : o;
+    const size_t o = tape_partials_offset(B, max_steps, elem, H, L);
+    if (!tuned_shape(H, L)) return o;            // the generic path flushes coalesced atomics (hode_generic.hip)
+    const int P = 9 * H + H + (L - 1) * (H * H + H) + 6 * H + 6;
+    return o + (size_t)adj_partial_rows(B) * adj_partial_rowlen(P) * elem;
 }
 #ifdef HODE_LAB
 int launch_solve_bwd_split(hipStream_t s, const AdjArgs<float> &a, int L, int method);   // lab/hode_solve_bwd_split.hip (fp32, tuned shapes)

@@ -254,14 +254,23 @@ __global__ __launch_bounds__(WTREG ? 256 : 64 * kBwdWaves, (sizeof(R) == 4 && !W
         if (lane < 6) a.gx0[(size_t)b * 6 + lane] = lam;
     }
 
+    // ---- epilogue: ONE gradient row per workgroup, no floating-point atomics ------------------------------------------------
+    // The 8 waves add their accumulators in a FIXED order into the (now dead) LDS image of the transposed matrices --
+    // [layer][row][col], natural order -- and the workgroup stores the sums, coalesced, to its row of a.partials; a second
+    // kernel (adj_reduce_kernel) adds the rows of a parameter set in workgroup order into gnn / gode.  Every summation order is
+    // fixed by the launch geometry: the same inputs give the same bits (the reference's CPU training is deterministic; the
+    // 256 x 12 k coalesced atomics this replaces were not).  Without a partials area (a caller with more parameter sets than
+    // rows) the sums leave through atomics as before.
+    const int nthreads = 64 * kWaves;
+    const size_t rowlen = adj_partial_rowlen(a.P);
+    const int wg = blockIdx.y * gridDim.x + blockIdx.x;
+    R *__restrict__ prow = a.partials ? a.partials + (size_t)wg * rowlen : nullptr;
+    auto emit = [&](R *__restrict__ gp, size_t off, R v) {          // gp = the set's slice of gnn (atomic route)
+        if (prow) prow[off] = v; else atomic_add(gp + off, v);
+    };
     if (a.gnn) {
-        // Cross-wave reduction in LDS before leaving the chip: the transposed-matrix image is dead now, its
-        // space becomes a [layer][row][col] sum of the workgroup's hidden-matrix accumulators, which is then
-        // flushed with COALESCED atomics (consecutive threads -> consecutive addresses): 256 workgroups x 12 k
-        // atomics instead of 2 048 waves x 12 k scattered ones (measured 414 MB of atomic write requests).
         R *__restrict__ gp = a.gnn + (size_t)set * a.P;
         constexpr int kHid = (NL > 1 ? NL - 1 : 0) * kMaxH * kMaxH;
-        const int nthreads = 64 * kWaves;
         __syncthreads();
         for (int i = threadIdx.x; i < kHid; i += nthreads) wt[i] = R(0);
         __syncthreads();
@@ -277,31 +286,69 @@ __global__ __launch_bounds__(WTREG ? 256 : 64 * kBwdWaves, (sizeof(R) == 4 && !W
         for (int i = threadIdx.x; i < kHid; i += nthreads) {
             const int l = i >> 12, row = (i >> 6) & 63, col = i & 63;
             if (row < a.H && col < a.H)
-                atomic_add(gp + 9 * a.H + a.H + (size_t)l * ((size_t)a.H * a.H + a.H) + (size_t)row * a.H + col, wt[i]);
+                emit(gp, 9 * a.H + a.H + (size_t)l * ((size_t)a.H * a.H + a.H) + (size_t)row * a.H + col, wt[i]);
         }
+        const int H = a.H;
+        const size_t off_out = (size_t)9 * H + H + (size_t)(NL - 1) * ((size_t)H * H + H);
+        auto emit_edge = [&](int slot, int j, R v) {
+            if (slot < ES::b) { if (j < H) emit(gp, j * 9 + slot, v); }
+            else if (slot < ES::w5) {
+                const int l = slot - ES::b;
+                if (j < H) emit(gp, 9 * H + (l == 0 ? 0 : H + (size_t)(l - 1) * ((size_t)H * H + H) + (size_t)H * H) + j, v);
+            } else if (slot < ES::b5) { if (j < H) emit(gp, off_out + (slot - ES::w5) * H + j, v); }
+            else if (j < 6) emit(gp, off_out + 6 * H + j, v);
+        };
         if constexpr (kEdgeLds<R>) {
-            // edge accumulators: sum the per-wave LDS tables, one atomic per parameter per workgroup
+            // edge accumulators: the per-wave LDS tables summed in wave order
             const R *edgeG0 = rowsT + 8 * kWave + ES::count * kWave;
-            const int H = a.H;
-            const size_t off_out = (size_t)9 * H + H + (size_t)(NL - 1) * ((size_t)H * H + H);
             for (int i = threadIdx.x; i < ES::count * kWave; i += nthreads) {
-                const int slot = i >> 6, j = i & 63;
                 R v = R(0);
                 for (int w = 0; w < kWaves; ++w) v += edgeG0[(size_t)w * ES::count * kWave + i];
-                if (slot < ES::b) { if (j < H) atomic_add(gp + j * 9 + slot, v); }
-                else if (slot < ES::w5) {
-                    const int l = slot - ES::b;
-                    if (j < H) atomic_add(gp + 9 * H + (l == 0 ? 0 : H + (size_t)(l - 1) * ((size_t)H * H + H) + (size_t)H * H) + j, v);
-                } else if (slot < ES::b5) { if (j < H) atomic_add(gp + off_out + (slot - ES::w5) * H + j, v); }
-                else if (j < 6) atomic_add(gp + off_out + 6 * H + j, v);
+                emit_edge(i >> 6, i & 63, v);
             }
         } else {
-            edge_flush<R, NL>(E, gp, a.H, lane);
+            // edge accumulators live in registers (fp64 parity build): through the dead image, wave by wave
+            __syncthreads();
+            for (int i = threadIdx.x; i < ES::count * kWave; i += nthreads) wt[i] = R(0);
+            __syncthreads();
+            for (int w = 0; w < kWaves; ++w) {
+                if (wave == w) {
+#pragma unroll
+                    for (int sl = 0; sl < ES::count; ++sl) wt[sl * kWave + lane] += E.G(sl);
+                }
+                __syncthreads();
+            }
+            for (int i = threadIdx.x; i < ES::count * kWave; i += nthreads) emit_edge(i >> 6, i & 63, wt[i]);
         }
     }
     if constexpr (GODE) {
-        if (a.gode && lane < 17) atomic_add(a.gode + 17 * set + lane, go);
+        if (a.gode) {
+            // lane p < 17 of every wave holds its share of d/d(ode constant p): summed in wave order
+            __syncthreads();
+            if (lane < 17) wt[wave * 32 + lane] = go;
+            __syncthreads();
+            if (threadIdx.x < 17) {
+                R v = R(0);
+                for (int w = 0; w < kWaves; ++w) v += wt[w * 32 + threadIdx.x];
+                if (prow) prow[a.P + threadIdx.x] = v; else atomic_add(a.gode + 17 * set + threadIdx.x, v);
+            }
+        }
     }
+}
+
+// second pass of the adjoint's gradient reduction: row sums in workgroup order (fixed), added to gnn / gode
+template <typename R>
+__global__ __launch_bounds__(256) void adj_reduce_kernel(const R *__restrict__ partials, const int rowlen, const int blocks_per_set, const int P,
+                                                         R *__restrict__ gnn, R *__restrict__ gode)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x, set = blockIdx.y;
+    if (i >= P + 17) return;
+    if (i < P ? gnn == nullptr : gode == nullptr) return;
+    const R *__restrict__ p = partials + (size_t)set * blocks_per_set * rowlen + i;
+    R v = R(0);
+    for (int w = 0; w < blocks_per_set; ++w) v += p[(size_t)w * rowlen];
+    if (i < P) gnn[(size_t)set * P + i] += v;
+    else gode[(size_t)set * 17 + (i - P)] += v;
 }
 
 // compute units of the current device (one adjoint workgroup per CU); queried once per device, never assumed
@@ -333,7 +380,14 @@ template <typename R, int NL, bool GODE, bool WTREG, bool GD> static int launch_
     auto kern = solve_bwd_kernel<R, NL, GODE, WTREG, GD>;
     if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return HODE_ELAUNCH;
-    hipLaunchKernelGGL(kern, grid, block, lds, s, a, method);
+    AdjArgs<R> a2 = a;
+    if (blocks * a.n_sets > a.partial_rows) a2.partials = nullptr;       // more parameter sets than rows: atomics
+    hipLaunchKernelGGL(kern, grid, block, lds, s, a2, method);
+    if (a2.partials && (a.gnn || (GODE && a.gode))) {
+        const int rowlen = (int)adj_partial_rowlen(a.P);
+        hipLaunchKernelGGL(adj_reduce_kernel<R>, dim3((a.P + 17 + 255) / 256, a.n_sets), dim3(256), 0, s, a2.partials, rowlen, blocks, a.P,
+                           a.gnn, GODE ? a.gode : (R *)nullptr);
+    }
     return hipGetLastError() == hipSuccess ? HODE_OK : HODE_ELAUNCH;
 }
 

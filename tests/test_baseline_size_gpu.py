@@ -60,7 +60,8 @@ def hode():
 def _failure_cohort():
     """256 patients of bench.py's z-scored cohort (x0 ~ N(0,1)^6, seed 4242, the benchmark's meals) + the reference's stress states
     (tests/test_ode_jacobians.py:173-206 `extreme_states`; tests/test_gradient_correctness.py:211-256 x0 = 10 randn, meals up to
-    50, tVNS = 1) + states that cannot be integrated at all: NaN / Inf in x0, a NaN in the meal row half way, an fp32 overflow."""
+    50, tVNS = 1) + states that cannot be integrated at all: NaN / Inf in x0, a NaN in the meal row half way, states exactly ON
+    the poles GLP1 = -EC_50 and G = -K_m (models/ode_core.py:129-135 divides by zero there; SURVEY 8a: "no clamping")."""
     _, t, meal, tvns = (v.numpy().astype(np.float64) for v in bench.synth_cohort(4096, 1000))
     xz = torch.randn(4096, 6, generator=torch.Generator().manual_seed(4242)).numpy().astype(np.float64)[:256]
     mz, vz = meal[:256].copy(), tvns[:256].copy()
@@ -76,8 +77,9 @@ def _failure_cohort():
     xb[0, 2] = np.nan                    # missing value in the initial state
     xb[1, 0] = np.inf
     mb[2, 100] = np.nan                  # missing value in an input row: fails in interval 99, rows 0..99 are good
-    xb[3, 5] = 3.0e38                    # FFA at the edge of fp32: (-p7 - p8 I + p9 G) F overflows in the first stage combination
+    xb[3, 3] = -50.0                     # GLP1 = -EC_50: GLP1 / (EC_50 + GLP1) = -50 / 0, non-finite at every step size
     mb[4, 7] = 1.0                       # healthy neighbours in the same launch
+    xb[5, 0] = -7.0                      # G = -K_m: V_max G / (K_m + G)
     x0 = np.concatenate([xz, xs, xb])
     return x0, t, np.concatenate([mz, ms, mb]), np.concatenate([vz, vs, vb])
 
@@ -138,7 +140,8 @@ def test_cfg2_failure_statuses_rows_and_adjoint_match_oracle(hode, dtype):
     gtol = 2e-4 if dtype == torch.float32 else 1e-7
     assert relnorm(gx0[ok], gxo[ok]) < gtol
     # trajectories that failed at row 0 wrote nothing but row 0 itself: gx0 = the cotangent of row 0
-    dead = np.array([B - 8, B - 7])
+    dead = np.array([B - 8, B - 7, B - 5, B - 3])
+    assert np.all(sto[dead] >= 2) and np.all(sto[dead[:3]] == 3)      # (the G pole ends in a zero initial step: status 2)
     assert np.allclose(gx0[dead], c[dead, 0, :], rtol=1e-6, atol=0) and np.allclose(gxo[dead], c[dead, 0, :], rtol=1e-6, atol=0)
     # status-2 trajectories: the adjoint walks up to the pole; compare trajectory by trajectory, relative to each one's own size
     for b in np.nonzero(sto == 2)[0]:

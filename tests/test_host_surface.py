@@ -37,13 +37,13 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     assert hode.version().startswith("hode ")
     assert lib.hode_nn_param_count(64, 4) == 13510 and lib.hode_nn_param_count(32, 2) == 1574
-    # entries + interval indices + the stage tape (h_1..h_4 + state per stage)
-    assert hode.load().hode_tape_bytes(4096, 300, 4, 4) == 4096 * 300 * 36 + 4096 * 300 * 6 * (4 * 64 + 8) * 4
-    assert hode.load().hode_tape_bytes(4096, 300, 8, 4) == 4096 * 300 * 68 + 4096 * 300 * 6 * (4 * 64 + 8) * 8      # fp64: no delta tape
-    # the generic path (H > 64 or L > 4) records two rows of 64 per layer + the state: 2L x 64 + 8 reals per stage
-    assert lib.hode_tape_bytes_hl(32, 92, 4, 128, 5) == 32 * 92 * 36 + 32 * 92 * 6 * (10 * 64 + 8) * 4
-    assert lib.hode_tape_bytes_hl(32, 92, 4, 64, 4) == lib.hode_tape_bytes(32, 92, 4, 4)
-    assert lib.hode_nn_param_count(128, 5) == 68102 and lib.hode_tape_bytes_hl(1, 1, 4, 129, 5) == 0
+    # entries + interval indices + the stage tape (h_1..h_4 + state per stage) + the adjoint's gradient rows (one per workgroup,
+    # at most 1 024, never more than trajectories; row = P + 17 reals padded to a multiple of 64)
+    row = (13510 + 17 + 63) // 64 * 64
+    assert hode.load().hode_tape_bytes(4096, 300, 4, 4) == 4096 * 300 * 36 + 4096 * 300 * 6 * (4 * 64 + 8) * 4 + 1024 * row * 4
+    assert hode.load().hode_tape_bytes(4096, 300, 8, 4) == 4096 * 300 * 68 + 4096 * 300 * 6 * (4 * 64 + 8) * 8 + 1024 * row * 8
+    assert hode.load().hode_tape_bytes(64, 300, 4, 4) == 64 * 300 * 36 + 64 * 300 * 6 * (4 * 64 + 8) * 4 + 64 * row * 4
+    assert hode.load().hode_tape_bytes_hl(64, 300, 4, 128, 5) == 64 * 300 * 36 + 64 * 300 * 6 * (2 * 5 * 64 + 8) * 4      # generic path: no rows
 
 
 def test_argument_validation_without_gpu():

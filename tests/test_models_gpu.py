@@ -659,3 +659,36 @@ def test_elbo_sharded_over_two_ranks_equals_single_process(M, golden_dir):
         assert abs(e1 - e0) <= 1e-9 * abs(e0)
         assert relnorm(g1, g0) < 2e-6
     assert res[0][1] == res[1][1] and np.array_equal(res[0][2], res[1][2])      # replicas stay bit-identical
+
+
+def test_train_step_is_bit_reproducible_run_to_run():
+    """the reference's CPU training is deterministic.  The tuned adjoint sums its parameter gradient without
+    floating-point atomics (one row per workgroup, rows added in workgroup order by a second pass), so three fused training
+    steps from the same state give the same BITS twice -- parameters, Adam moments and losses -- and so does the gradient of
+    a batch with two parameter sets and ODE-constant gradients."""
+    import bench
+    import hode
+    d = torch.device("cuda")
+    B = 1024
+    x0, t, meal, tv = (v.to(d) for v in bench.synth_cohort(B, 4))
+    nn_t, ode = bench.synth_weights(0).to(d), bench.ODE_DEFAULT.to(d)
+    obs, student = bench.train_problem(d, x0, t, meal, tv, ode, nn_t, 0)
+    runs = []
+    for _ in range(2):
+        state = hode.train.TrainState(student.clone())
+        n_el = obs.numel()
+
+        def compute(p):
+            ls, gnn, gode, _ = hode.train.hip_loss_and_grads(p, ode, x0, t, meal, tv, obs, 64, 4, n_el, state=state)
+            return ls, gnn, gode, n_el
+        losses = [float(hode.train.train_step(state, compute, lr=1e-3, max_norm=5.0)) for _ in range(3)]
+        runs.append((state.p.clone(), state.m.clone(), state.v.clone(), losses))
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1]) and torch.equal(runs[0][2], runs[1][2])
+    assert runs[0][3] == runs[1][3] and runs[0][3][-1] < runs[0][3][0]
+    nn2, ode2 = torch.cat([student, 0.9 * student]), torch.cat([ode, ode])
+    sol = hode.solve_fwd(x0[:300], t, meal[:300], tv[:300], None, ode2, nn2, 64, 4, n_sets=2, want_tape=True)
+    c = torch.randn(sol.y.shape, device=d, generator=torch.Generator(d).manual_seed(1))
+    a = hode.solve_bwd(sol, c, want_gode=True)
+    b = hode.solve_bwd(sol, c, want_gode=True)
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
