@@ -49,6 +49,10 @@ int launch_solve_fwd_quad(hipStream_t s, const SolveArgs<float> &a, int L, int m
 int launch_solve_fwd_rows(hipStream_t s, const SolveArgs<float> &a, int L, int method); // lab/hode_solve_fwd_rows.hip (fp32, L = 2..4)
 #endif
 template <typename R> int launch_solve_bwd(hipStream_t s, const AdjArgs<R> &a, int L, int method);
+// wave-specialised fp32 adjoint (hode_solve_bwd_ws.hip; L = 2..4, needs the partial rows); HODE_EUNSUPPORTED -> solve_bwd_kernel
+int launch_solve_bwd_ws(hipStream_t s, const AdjArgs<float> &a, int L, int method, int cus);
+// second pass of the gradient reduction: rows of a.partials added in workgroup order (hode_solve_bwd.hip)
+void launch_adj_reduce(hipStream_t s, const float *partials, int rowlen, int blocks_per_set, int n_sets, int P, float *gnn, float *gode);
 template <typename R> int launch_rhs_fwd(hipStream_t s, const RhsArgs<R> &a, int L);
 template <typename R> int launch_rhs_bwd(hipStream_t s, const RhsArgs<R> &a, int L);
 // generic network path (hode_generic.hip): H <= 128, L <= 8, weights streamed from L2

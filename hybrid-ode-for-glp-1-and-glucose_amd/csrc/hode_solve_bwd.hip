@@ -351,6 +351,11 @@ __global__ __launch_bounds__(256) void adj_reduce_kernel(const R *__restrict__ p
     else gode[(size_t)set * 17 + (i - P)] += v;
 }
 
+void launch_adj_reduce(hipStream_t s, const float *partials, int rowlen, int blocks_per_set, int n_sets, int P, float *gnn, float *gode)
+{
+    hipLaunchKernelGGL(adj_reduce_kernel<float>, dim3((P + 17 + 255) / 256, n_sets), dim3(256), 0, s, partials, rowlen, blocks_per_set, P, gnn, gode);
+}
+
 // compute units of the current device (one adjoint workgroup per CU); queried once per device, never assumed
 static int device_cu_count()
 {
@@ -423,8 +428,22 @@ template <typename R, int NL> static int launch_bwd_nl(hipStream_t s, const AdjA
     return a.gode ? launch_bwd_k<R, NL, true, false>(s, a, method) : launch_bwd_k<R, NL, false, false>(s, a, method);
 }
 
+// HODE_BWD=fused (any build): the one-role kernel also for the fp32 shapes the wave-specialised kernel takes -- A/B timing and
+// the parity test that compares the two (read once per process; not on the product's default path)
+static bool bwd_force_fused()
+{
+    static const bool v = [] { const char *e = getenv("HODE_BWD"); return e && e[0] == 'f'; }();
+    return v;
+}
+
 template <typename R> int launch_solve_bwd(hipStream_t s, const AdjArgs<R> &a, int L, int method)
 {
+    if constexpr (sizeof(R) == 4) {
+        if (L >= 2 && !bwd_force_fused()) {
+            const int rc = launch_solve_bwd_ws(s, a, L, method, device_cu_count());
+            if (rc != HODE_EUNSUPPORTED) return rc;
+        }
+    }
 #ifdef HODE_LAB
     if constexpr (sizeof(R) == 4) {
         if (L >= 2 && a.tape_delta && split_adjoint_enabled() && !bwd_wt_in_regs()) return launch_solve_bwd_split(s, a, L, method);

@@ -655,11 +655,17 @@ np.savez({out!r}, gx0=gx0.cpu().numpy(), gnn=gnn.cpu().numpy(), gode=gode.cpu().
          st1=s1.status.cpu().numpy(), g1x=g1x.cpu().numpy(), g1n=g1n.cpu().numpy())
 """
     res = {}
-    for mode in ("split", "fused"):
-        env = dict(os.environ, HODE_BWD=mode, HODE_LIB=LAB_LIB) if mode == "split" else {k: v for k, v in os.environ.items() if k != "HODE_LIB"}
+    # "ws" = the product library: the wave-specialised adjoint (csrc/hode_solve_bwd_ws.hip); "fused" = the one-role kernel it
+    # replaced for fp32 (still the fp64 kernel), "split" = the two-kernel experiment -- both through the lab library's switch
+    for mode in ("split", "fused", "ws"):
+        env = dict(os.environ, HODE_BWD=mode, HODE_LIB=LAB_LIB) if mode != "ws" else {k: v for k, v in os.environ.items() if k != "HODE_LIB"}
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         res[mode] = dict(np.load(out))
+    for key in ("gx0", "gnn", "gnnb", "g1x", "g1n"):
+        assert relnorm(res["ws"][key], res["fused"][key]) < 1e-5, key
+    assert relnorm(res["ws"]["gode"], res["fused"]["gode"]) < 1e-4 and np.array_equal(res["ws"]["st1"], res["fused"]["st1"])
+    assert np.array_equal(res["ws"]["gnn"], res["ws"]["gnnb"])          # no atomics: walking the tape twice gives the same bits
     a, b = res["split"], res["fused"]
     assert relnorm(a["gx0"], b["gx0"]) < 1e-5 and relnorm(a["gnn"], b["gnn"]) < 1e-5 and relnorm(a["gode"], b["gode"]) < 1e-4
     assert relnorm(a["gnnb"], a["gnn"]) < 1e-5
