@@ -7,41 +7,45 @@
 // Why.  The one-role kernel keeps 192 gradient accumulators in every wave: 256 VGPRs, 2 waves per SIMD, where a DPP FMA costs
 // 3.8 cycles of SIMD time (2.9 at 4 waves), and PMC shows its waves parked in s_waitcnt 36 % of the time with no third wave to
 // fill in.  The accumulators are sums over ALL stages of ALL trajectories -- they do not have to live where the cotangent is
-// propagated.  So a workgroup of 9 + 2 (NL - 1) waves splits the work by ROLE:
+// propagated.  A workgroup of 16 waves (one per CU, 4 per SIMD, <= 128 VGPRs) splits the work by ROLE:
 //
-//   P  8 propagation waves   one trajectory each.  Per stage: record (h_1..h_NL, stage state) by LDS-DMA, kb, mechanistic
-//                            J^T, delta_NL .. delta_1 through the transposed matrices (LDS image, rotating-operand order).
-//                            No gradient accumulators: ~100 VGPRs.  Publishes delta_1..delta_NL, kb, t, tVNS in an LDS
-//                            hand-off slot (1.5 KB, double buffered).
-//   A  2 (NL - 1) waves      A(m, g) owns dW of hidden matrix m -- 64 accumulators -- for the P-waves 4 g .. 4 g + 3:
-//                            dW_m += delta_{m+1} (x) h_m, 64 v_fmac_f32_dpp per P-wave and stage, operands straight from
-//                            LDS (the P-wave's record and hand-off slot).
-//   E  1 wave                first / last layer and bias gradients of all 8 P-waves (16 + NL accumulators).
+//   P  8 propagation waves   U (1 or 2) trajectories each, interleaved instruction by instruction: a lone wave issues a
+//                            dependent instruction every ~9 cycles, two independent chains fill each other's gaps, and the two
+//                            share every 16-byte read of the transposed matrices.  Per stage and trajectory: record (h_1..h_NL,
+//                            stage state) by LDS-DMA, kb, mechanistic J^T, delta_NL .. delta_1 through the transposed matrices
+//                            (LDS image, rotating-operand order).  No gradient accumulators.  Publishes delta_1..delta_NL, kb,
+//                            t, tVNS in an LDS hand-off slot (1.1 KB per trajectory, double buffered).
+//   A  8 accumulation waves  A_j owns dW of hidden matrix j % (NL-1) -- 64 accumulators -- for its share of the 8 U trajectory
+//                            slots: dW_m += delta_{m+1} (x) h_m, 64 v_fmac_f32_dpp per slot and stage, operands straight
+//                            from LDS (the slot's record and hand-off), + the bias of that layer; A_4..A_7 also keep the
+//                            first / last layer gradients (17 accumulators) of a quarter of the slots each.
 //
-// Everything is in lock step: one s_barrier per stage.  In iteration i the P-waves process their stage i while A / E consume
-// what was published in iteration i - 1 (hand-off double buffered, record ring of three slots), so nobody polls and every
-// wave reaches every barrier: the iteration count is the maximum over the P-waves of their total stage count, + 1.
-// All 15 waves fit one CU at 128 VGPRs (4 waves per SIMD); LDS 104 KB.
+// Everything is in lock step: one s_barrier per stage.  In iteration i the P-waves process stage i of their trajectories while
+// the A-waves consume what was published in iteration i - 1 (hand-off double buffered, record ring of three slots), so nobody
+// polls and every wave reaches every barrier: the iteration count is the maximum over the slots of their total stage count, + 1.
+// With U = 2 a 4 096-trajectory batch is ONE round of 16 trajectories per CU.
 //
-// Determinism: A(m, g) adds its four P-waves' products in a fixed order, the two groups and the eight go-registers are summed
-// in a fixed order, the workgroup writes ONE gradient row to a.partials and adj_reduce_kernel adds the rows in workgroup
-// order: no floating-point atomics anywhere, the same inputs give the same bits.
+// Determinism: every A-wave adds its slots' products in slot order, the waves of a matrix are summed in rank order, the workgroup
+// writes ONE gradient row to a.partials and adj_reduce_kernel adds the rows in workgroup order: no floating-point atomics
+// anywhere, the same inputs give the same bits.
 #include "hode_device.h"
 #include "hode_kernels.h"
+#include <cstdlib>
 
 namespace hode {
 
 namespace {
 
 constexpr int kWsP = 8;                                    // propagation waves per workgroup
+constexpr int kWsA = 8;                                    // accumulation waves per workgroup
+constexpr int kWsWaves = kWsP + kWsA;
 constexpr int kWsRing = 3;                                 // record ring: being DMA'd | being propagated | being accumulated
-template <int NL> constexpr int ws_waves() { return kWsP + 2 * (NL - 1) + 1; }
 template <int NL> constexpr int ws_rec_elems() { return (NL + 1) * kWave; }          // NL rows + the stage state (8 of 64 used)
-template <int NL> constexpr int ws_hand_elems() { return (NL + 1) * kWave; }         // delta_1..delta_NL + {kb[6], t, tvns | valid, slot}
-template <int NL> constexpr size_t ws_lds_elems()
+template <int NL> constexpr int ws_hand_elems() { return NL * kWave + 16; }          // delta_1..delta_NL + {kb[6], t, tvns}
+template <int NL, int U> constexpr size_t ws_lds_elems()
 {
-    return (size_t)(NL - 1) * kMaxH * kMaxH + 8 * kWave + (size_t)kWsP * kWsRing * ws_rec_elems<NL>() +
-           (size_t)kWsP * 2 * ws_hand_elems<NL>() + 64;
+    return (size_t)(NL - 1) * kMaxH * kMaxH + 8 * kWave + (size_t)kWsP * U * kWsRing * ws_rec_elems<NL>() +
+           (size_t)kWsP * U * 2 * ws_hand_elems<NL>() + 2 * 16 + 16;
 }
 
 __device__ __forceinline__ float inp_at_w(const float *__restrict__ p, int mode, int b, int T, int k)
@@ -80,11 +84,12 @@ template <int G> __device__ __forceinline__ void ws_wt_group(const Vec4<float> (
     HODE_WS_FM("v_fmac_f32", "");
 #undef HODE_WS_FM
 }
-__device__ __forceinline__ float ws_wt_mul(const float *__restrict__ wt, int lane, float d)
+// U = 1
+__device__ __forceinline__ void ws_wt_mul(const float *__restrict__ wt, int lane, const float (&d)[1], float (&out)[1])
 {
     const Vec4<float> *wt4 = reinterpret_cast<const Vec4<float> *>(wt);
     float Rd[4];
-    rows_replicate(d, Rd);
+    rows_replicate(d[0], Rd);
     // rows 4 G .. 4 G + 3 of the image feed group G (r = 16 G + 4 i + c  ->  q = G, n = 4 i + c)
     Vec4<float> w0[4], w1[4];
 #pragma unroll
@@ -106,28 +111,66 @@ __device__ __forceinline__ float ws_wt_mul(const float *__restrict__ wt, int lan
     ws_wt_group<2>(w0, Rd, acc);
     __builtin_amdgcn_sched_barrier(0);
     ws_wt_group<3>(w1, Rd, acc);
-    return (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    out[0] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+}
+// U = 2: the same sixteen 16-byte reads feed both trajectories' products (half the LDS traffic per trajectory), and the two
+// accumulator sets are independent instruction chains
+__device__ __forceinline__ void ws_wt_mul(const float *__restrict__ wt, int lane, const float (&d)[2], float (&out)[2])
+{
+    const Vec4<float> *wt4 = reinterpret_cast<const Vec4<float> *>(wt);
+    float Ra[4], Rb[4];
+    rows_replicate(d[0], Ra);
+    rows_replicate(d[1], Rb);
+    Vec4<float> w0[4], w1[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w0[i] = wt4[(0 + i) * kMaxH + lane];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w1[i] = wt4[(4 + i) * kMaxH + lane];
+    float aa[4] = {0.f, 0.f, 0.f, 0.f}, ab[4] = {0.f, 0.f, 0.f, 0.f};
+    __builtin_amdgcn_sched_barrier(0);
+    ws_wt_group<0>(w0, Ra, aa);
+    ws_wt_group<0>(w0, Rb, ab);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w0[i] = wt4[(8 + i) * kMaxH + lane];
+    __builtin_amdgcn_sched_barrier(0);
+    ws_wt_group<1>(w1, Ra, aa);
+    ws_wt_group<1>(w1, Rb, ab);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w1[i] = wt4[(12 + i) * kMaxH + lane];
+    __builtin_amdgcn_sched_barrier(0);
+    ws_wt_group<2>(w0, Ra, aa);
+    ws_wt_group<2>(w0, Rb, ab);
+    __builtin_amdgcn_sched_barrier(0);
+    ws_wt_group<3>(w1, Ra, aa);
+    ws_wt_group<3>(w1, Rb, ab);
+    out[0] = (aa[0] + aa[1]) + (aa[2] + aa[3]);
+    out[1] = (ab[0] + ab[1]) + (ab[2] + ab[3]);
 }
 
 }  // namespace
 
-template <int NL, bool GODE, bool GD>
-__global__ __launch_bounds__(64 * ws_waves<NL>()) void solve_bwd_ws_kernel(const AdjArgs<float> a, const int method)
+template <int NL, int U, bool GODE, bool GD>
+__global__ __launch_bounds__(64 * kWsWaves) void solve_bwd_ws_kernel(const AdjArgs<float> a, const int method_dbg)
 {
     using R = float;
     using ES = EdgeSlots<NL>;
     static_assert(NL >= 2 && NL <= 4, "the specialised adjoint needs at least one hidden matrix");
-    constexpr int kWaves = ws_waves<NL>();
-    constexpr int kA = 2 * (NL - 1);
+    static_assert(U == 1 || U == 2, "one or two trajectories per propagation wave");
+    constexpr int NM = NL - 1;                            // hidden matrices
+    constexpr int NT = kWsP * U;                          // trajectory slots of the workgroup
     constexpr int kRec = ws_rec_elems<NL>();
     constexpr int kHand = ws_hand_elems<NL>();
     constexpr int kSlot = NL * kWave + 8;                 // stage record on the tape: NL rows + 8 reals of stage state
+    constexpr int kMaxRank = (kWsA - 1) / NM + 1;         // accumulation waves of matrix 0 (the most any matrix has)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    R *wt = reinterpret_cast<R *>(smem_raw);              // [(NL-1)][64*64] transposed hidden matrices, rotating-operand order
-    R *rowsT = wt + (size_t)(NL - 1) * kMaxH * kMaxH;     // [8][64] transposed tableau rows
-    R *recs = rowsT + 8 * kWave;                          // [kWsP][kWsRing][kRec]
-    R *hands = recs + (size_t)kWsP * kWsRing * kRec;      // [kWsP][2][kHand]
-    int *niter = reinterpret_cast<int *>(hands + (size_t)kWsP * 2 * kHand);
+    R *wt = reinterpret_cast<R *>(smem_raw);              // [NM][64*64] transposed hidden matrices, rotating-operand order
+    R *rowsT = wt + (size_t)NM * kMaxH * kMaxH;           // [8][64] transposed tableau rows
+    R *recs = rowsT + 8 * kWave;                          // [NT][kWsRing][kRec]
+    R *hands = recs + (size_t)NT * kWsRing * kRec;        // [NT][2][kHand]
+    int *tags = reinterpret_cast<int *>(hands + (size_t)NT * 2 * kHand);      // [2][16]: 0 = nothing published, else 1 + ring slot
+    int *niter = tags + 2 * 16;
 
     const int lane = threadIdx.x & 63;
     const int c8 = lane & 7, grp = lane >> 3, p16 = lane & 15;
@@ -135,55 +178,69 @@ __global__ __launch_bounds__(64 * ws_waves<NL>()) void solve_bwd_ws_kernel(const
     const int set = blockIdx.y;
     const int T = a.T;
     const int per_set = a.B / a.n_sets;
+#ifdef HODE_LAB
+    const int dbg = method_dbg >> 8;                      // lab library: timing experiments (HODE_WS_DBG), results are WRONG with any bit set
+    const int method = method_dbg & 0xff;
+#else
+    constexpr int dbg = 0;
+    const int method = method_dbg;
+#endif
     const int S = kTableau[method].S;
     const R *__restrict__ nn_set = a.nn_p + (size_t)set * a.P;
-    const bool isP = wave < kWsP, isA = wave >= kWsP && wave < kWsP + kA;
+    const bool isP = wave < kWsP;
 
-    wt_rot_store<R>(wt, nn_set, a.H, NL - 1, threadIdx.x, 64 * kWaves);
-    tableau_rowsT_store<R>(rowsT, method, threadIdx.x, 64 * kWaves);
+    wt_rot_store<R>(wt, nn_set, a.H, NM, threadIdx.x, 64 * kWsWaves);
+    tableau_rowsT_store<R>(rowsT, method, threadIdx.x, 64 * kWsWaves);
+    if (threadIdx.x < 2 * 16) tags[threadIdx.x] = 0;
     if (threadIdx.x == 0) *niter = 0;
-    // hand-off slots start invalid
-    for (int i = threadIdx.x; i < kWsP * 2; i += 64 * kWaves) reinterpret_cast<int *>(hands + (size_t)i * kHand + NL * kWave)[8] = 0;
     __syncthreads();
-    // iterations = the longest propagation wave's number of stages (+ 1: accumulation runs one iteration behind)
+    // iterations = the longest slot's number of stages (+ 1: accumulation runs one iteration behind).  Slot t = U wave + u takes
+    // the trajectories t, t + NT, ... of this workgroup's share (slot-major, like the one-role kernel's wave-major deal)
     if (isP) {
-        int tot = 0;
-        for (int bi = wave * gridDim.x + blockIdx.x; bi < per_set; bi += gridDim.x * kWsP) {
-            const int nb = a.nsteps[set * per_set + bi];
-            tot += (nb < a.max_steps ? nb : a.max_steps) * S;
+        int mx = 0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            int tot = 0;
+            for (int bi = (wave * U + u) * gridDim.x + blockIdx.x; bi < per_set; bi += gridDim.x * NT) {
+                const int nb = a.nsteps[set * per_set + bi];
+                tot += (nb < a.max_steps ? nb : a.max_steps) * S;
+            }
+            mx = tot > mx ? tot : mx;
         }
-        if (lane == 0) atomicMax(niter, tot);
+        if (lane == 0) atomicMax(niter, mx);
     }
     __syncthreads();
     const int n_iter = *niter + 1;
 
-    // ---- the three roles: each has its OWN loop (its registers are live in its branch only: 64 accumulators here, the
-    //      propagation state there), every loop executes the same n_iter barriers -------------------------------------------
+    // ---- the two roles: each has its OWN loop (its registers are live in its branch only: 64 accumulators here, the
+    //      propagation state there), both loops execute the same n_iter barriers ---------------------------------------------
     R gw[kMaxH];                                          // A: dW of one hidden matrix (rotating-operand register order)
-    R ge[ES::count];                                      // E: first / last layer and bias gradients
+    R gb = 0.f;                                           // A: bias of that matrix's layer
+    R ge[17];                                             // A_4..7: W1 (9), b_1, Wout (6), bout
     R go = 0.f;                                           // P: lane p < 17 holds d/d(ode constant p)
+    const int aj = wave - kWsP;                           // accumulation wave index
+    const int am = aj % NM, ar = aj / NM;                 // its matrix and its rank among that matrix's waves
+    const int an = (kWsA - 1 - am) / NM + 1;              // accumulation waves of matrix am
     if (isP) {
-        // edge weights in registers (no accumulators here: there is room), trajectory / step / stage cursors
+        // edge weights in registers (no accumulators here: there is room); per trajectory: step / stage cursors
         R w1[9], w5[6];
         OdeP<R> o;
-        R lam = 0.f, ZZ = 0.f;
-        int bi_next = wave * gridDim.x + blockIdx.x, b = 0, n = 0, st = -1, s = 0, knext = 0, k = 0, cur = 0;
-        bool active = false, ok = true;
-        R tc = 0.f, h = 0.f, t0 = 0.f, inv_len = 0.f, v0 = 0.f, dv = 0.f, d0 = 0.f, dd = 0.f;
-        const R *__restrict__ tg = nullptr, *__restrict__ tape = nullptr, *__restrict__ stg = nullptr, *__restrict__ gyb = nullptr;
-        const int *__restrict__ tseg = nullptr;
-        R *rec = recs + (size_t)wave * kWsRing * kRec;
-        R *hand = hands + (size_t)wave * 2 * kHand;
+        R lam[U], ZZ[U], tc[U], h[U], t0[U], inv_len[U], v0[U], dv[U], d0[U], dd[U];
+        int bi_next[U], b[U], n[U], st[U], s[U], knext[U], k[U], cur[U];
+        bool active[U], ok[U];
+        const R *__restrict__ stg[U];
         {
             const R live = (lane < a.H) ? 1.f : 0.f;
             const int j = (lane < a.H) ? lane : a.H - 1;
-            const R *pout = nn_set + 9 * a.H + a.H + (size_t)(NL - 1) * ((size_t)a.H * a.H + a.H);
+            const R *pout = nn_set + 9 * a.H + a.H + (size_t)NM * ((size_t)a.H * a.H + a.H);
 #pragma unroll
             for (int i = 0; i < 9; ++i) w1[i] = live * nn_set[j * 9 + i];
 #pragma unroll
             for (int q = 0; q < 6; ++q) w5[q] = live * pout[q * a.H + j];
             ode_load(o, a.ode_p + 17 * set);
         }
+        auto rec_of = [&](int u) -> R * { return recs + (size_t)(wave * U + u) * kWsRing * kRec; };
+        auto hand_of = [&](int u, int par) -> R * { return hands + ((size_t)(wave * U + u) * 2 + par) * kHand; };
         auto rec_dma = [&](const R *__restrict__ src, R *dst) {
 #pragma unroll
             for (int l = 0; l < NL; ++l)
@@ -191,227 +248,249 @@ __global__ __launch_bounds__(64 * ws_waves<NL>()) void solve_bwd_ws_kernel(const
             if (lane < 8)
                 __builtin_amdgcn_global_load_lds(src + NL * kWave + lane, (__attribute__((address_space(3))) void *)(dst + NL * kWave), 4, 0, 0);
         };
-        auto inject = [&](int r) {                     // lam += dLoss/dy[b, r, :]  (six wave-uniform scalar loads)
-            const R *__restrict__ gr = gyb + (size_t)r * 6;
+        auto inject = [&](int u, int r) {              // lam += dLoss/dy[b, r, :]  (six wave-uniform scalar loads)
+            const R *__restrict__ gr = a.gy + ((size_t)b[u] * T + r) * 6;
             const R g0 = gr[0], g1 = gr[1], g2 = gr[2], g3 = gr[3], g4 = gr[4], g5 = gr[5];
-            lam += (c8 == 0) ? g0 : (c8 == 1) ? g1 : (c8 == 2) ? g2 : (c8 == 3) ? g3 : (c8 == 4) ? g4 : (c8 == 5) ? g5 : 0.f;
+            lam[u] += (c8 == 0) ? g0 : (c8 == 1) ? g1 : (c8 == 2) ? g2 : (c8 == 3) ? g3 : (c8 == 4) ? g4 : (c8 == 5) ? g5 : 0.f;
         };
         // rows 0..kf of a trajectory are (copies of) x0: their cotangents close the trajectory (see solve_bwd_kernel)
-        auto finish_traj = [&]() {
+        auto finish_traj = [&](int u) {
+            const R *__restrict__ tg = a.t + (a.t_batched ? (size_t)b[u] * T : 0);
             int kf = 0;
             while (kf + 1 < T && !(tg[kf + 1] > tg[kf])) ++kf;
-            for (int r = 0; r <= kf; ++r) inject(r);
-            if (lane < 6) a.gx0[(size_t)b * 6 + lane] = lam;
+            for (int r = 0; r <= kf; ++r) inject(u, r);
+            if (lane < 6) a.gx0[(size_t)b[u] * 6 + lane] = lam[u];
         };
-        // next trajectory of this wave that has steps on its tape; trajectories without any are closed on the spot
-        auto start_next = [&]() {
-            active = false;
-            while (bi_next < per_set) {
-                b = set * per_set + bi_next;
-                bi_next += gridDim.x * kWsP;
-                tg = a.t + (a.t_batched ? (size_t)b * T : 0);
-                tape = a.tape + (size_t)b * a.max_steps * 8;
-                tseg = a.tape_seg + (size_t)b * a.max_steps;
-                stg = a.tape_stage + (size_t)b * a.max_steps * 6 * kSlot;
-                gyb = a.gy + (size_t)b * T * 6;
-                n = a.nsteps[b] < a.max_steps ? a.nsteps[b] : a.max_steps;      // never walk past the tape
-                ok = a.status[b] == HODE_ST_OK;
-                lam = 0.f;
-                knext = T - 1;
-                if (n > 0) {
-                    st = n - 1;
-                    s = S - 1;
-                    rec_dma(stg + ((size_t)st * 6 + s) * kSlot, rec + cur * kRec);      // its first record
-                    active = true;
+        // next trajectory of this slot that has steps on its tape; trajectories without any are closed on the spot
+        auto start_next = [&](int u) {
+            active[u] = false;
+            while (bi_next[u] < per_set) {
+                b[u] = set * per_set + bi_next[u];
+                bi_next[u] += gridDim.x * NT;
+                stg[u] = a.tape_stage + (size_t)b[u] * a.max_steps * 6 * kSlot;
+                n[u] = a.nsteps[b[u]] < a.max_steps ? a.nsteps[b[u]] : a.max_steps;      // never walk past the tape
+                ok[u] = a.status[b[u]] == HODE_ST_OK;
+                lam[u] = 0.f;
+                knext[u] = T - 1;
+                if (n[u] > 0) {
+                    st[u] = n[u] - 1;
+                    s[u] = S - 1;
+                    rec_dma(stg[u] + ((size_t)st[u] * 6 + s[u]) * kSlot, rec_of(u) + cur[u] * kRec);      // its first record
+                    active[u] = true;
                     return;
                 }
-                finish_traj();
+                finish_traj(u);
             }
         };
-        start_next();
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            bi_next[u] = (wave * U + u) * gridDim.x + blockIdx.x;
+            cur[u] = 0; st[u] = -1; s[u] = 0; k[u] = 0; n[u] = 0; b[u] = 0; knext[u] = 0; ok[u] = true;
+            lam[u] = ZZ[u] = tc[u] = h[u] = t0[u] = inv_len[u] = v0[u] = dv[u] = d0[u] = dd[u] = 0.f;
+            stg[u] = a.tape_stage;
+            start_next(u);
+        }
 #pragma unroll 1
         for (int it = 0; it < n_iter; ++it) {
-            R *__restrict__ hd = hand + (it & 1) * kHand;
-            if (active) {
-                if (s == S - 1) {
-                    // ---- step header: cotangents of the grid rows this step produced, step and interval constants
-                    const int kraw = tseg[st];
-                    k = kraw & (kSegClosed - 1);
-                    int hi = knext;
-                    if (st == n - 1) {
+            const int par = it & 1;
+            // ---- step headers: cotangents of the grid rows a step produced, step and interval constants
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (active[u] && s[u] == S - 1) {
+                    const R *__restrict__ tg = a.t + (a.t_batched ? (size_t)b[u] * T : 0);
+                    const R *__restrict__ tape = a.tape + (size_t)b[u] * a.max_steps * 8;
+                    const int kraw = a.tape_seg[(size_t)b[u] * a.max_steps + st[u]];
+                    k[u] = kraw & (kSegClosed - 1);
+                    int hi = knext[u];
+                    if (st[u] == n[u] - 1) {
                         hi = T - 1;
-                        if (!ok) {                 // the last step of a FAILED trajectory: see solve_bwd_kernel
-                            hi = k;
+                        if (!ok[u]) {              // the last step of a FAILED trajectory: see solve_bwd_kernel
+                            hi = k[u];
                             if (kraw & kSegClosed) {
-                                hi = k + 1;
+                                hi = k[u] + 1;
                                 while (hi + 1 < T && !(tg[hi + 1] > tg[hi])) ++hi;
                             }
                         }
                     }
-                    for (int r = k + 1; r <= hi; ++r) inject(r);
-                    knext = k;
-                    tc = tape[(size_t)st * 8 + 0];
-                    h = tape[(size_t)st * 8 + 1];
-                    t0 = tg[k];
-                    const R t1 = tg[k + 1];
-                    v0 = inp_at_w(a.tvns, a.tvns_mode, b, T, k);
-                    const R v1 = inp_at_w(a.tvns, a.tvns_mode, b, T, k + 1);
-                    d0 = inp_at_w(a.gd, a.gd_mode, b, T, k);
-                    const R d1 = inp_at_w(a.gd, a.gd_mode, b, T, k + 1);
-                    inv_len = first_lane(1.f / (t1 - t0));
-                    dv = first_lane(v1 - v0);
-                    dd = first_lane(d1 - d0);
-                    ZZ = 0.f;
+                    for (int r = k[u] + 1; r <= hi; ++r) inject(u, r);
+                    knext[u] = k[u];
+                    tc[u] = tape[(size_t)st[u] * 8 + 0];
+                    h[u] = tape[(size_t)st[u] * 8 + 1];
+                    t0[u] = tg[k[u]];
+                    const R t1 = tg[k[u] + 1];
+                    v0[u] = inp_at_w(a.tvns, a.tvns_mode, b[u], T, k[u]);
+                    const R v1 = inp_at_w(a.tvns, a.tvns_mode, b[u], T, k[u] + 1);
+                    d0[u] = inp_at_w(a.gd, a.gd_mode, b[u], T, k[u]);
+                    const R d1 = inp_at_w(a.gd, a.gd_mode, b[u], T, k[u] + 1);
+                    inv_len[u] = first_lane(1.f / (t1 - t0[u]));
+                    dv[u] = first_lane(v1 - v0[u]);
+                    dd[u] = first_lane(d1 - d0[u]);
+                    ZZ[u] = 0.f;
                 }
-                // record (st, s) was DMA'd into ring slot `cur` one iteration ago (or at the start of the trajectory)
-                __builtin_amdgcn_s_waitcnt(0x0f70);            // vmcnt(0)
-                __builtin_amdgcn_wave_barrier();
-                const int slot = cur;
-                cur = (cur + 1 == kWsRing) ? 0 : cur + 1;
-                {
-                    // the next record of this trajectory goes to the slot behind: the one the accumulation waves read in the
-                    // PREVIOUS iteration (they are done with it: a barrier lies in between)
-                    const int ns_ = (s > 0) ? s - 1 : S - 1, nst = (s > 0) ? st : st - 1;
-                    if (nst >= 0) rec_dma(stg + ((size_t)nst * 6 + ns_) * kSlot, rec + cur * kRec);
-                }
-                const R *__restrict__ rc = rec + slot * kRec;
-                R hact[NL];
+            }
+            // the records to process now were DMA'd one iteration ago (or at the start of their trajectory)
+            __builtin_amdgcn_s_waitcnt(0x0f70);                // vmcnt(0)
+            __builtin_amdgcn_wave_barrier();
+            int slot[U];
 #pragma unroll
-                for (int l = 0; l < NL; ++l) hact[l] = rc[l * kWave + lane];
+            for (int u = 0; u < U; ++u) {
+                slot[u] = cur[u];
+                if (active[u]) {
+                    cur[u] = (cur[u] + 1 == kWsRing) ? 0 : cur[u] + 1;
+                    // the next record of the trajectory goes to the slot behind: the one the accumulation waves read in the
+                    // PREVIOUS iteration (they are done with it: a barrier lies in between)
+                    const int ns_ = (s[u] > 0) ? s[u] - 1 : S - 1, nst = (s[u] > 0) ? st[u] : st[u] - 1;
+                    if (nst >= 0) rec_dma(stg[u] + ((size_t)nst * 6 + ns_) * kSlot, rec_of(u) + cur[u] * kRec);
+                }
+            }
+            // ---- J^T kb for all U trajectories in ONE basic block (an idle slot computes on stale data; nothing of it is kept):
+            //      mechanistic part, then the cotangent through the layers; every delta goes to the hand-off slot
+            R hact[U][NL], kb[U], ts[U], tv[U], mech[U], d[U];
+            R *__restrict__ hd[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                hd[u] = hand_of(u, par);
+                const R *__restrict__ rc = rec_of(u) + slot[u] * kRec;
+#pragma unroll
+                for (int l = 0; l < NL; ++l) hact[u][l] = rc[l * kWave + lane];
                 const R Ys = rc[NL * kWave + c8];             // stage state, replicated layout
-                const R bw_s = rowsT[6 * kWave + s], c_s = rowsT[6 * kWave + 8 + s];
-                const R kb = h * rfma(bw_s, lam, group_sum8(rowsT[s * kWave + lane] * ZZ));
-                const R ts = rfma(c_s, h, tc);
-                const R al = (ts - t0) * inv_len;
-                const R gdv = rfma(al, dd, d0);
-                const R tv = rfma(al, dv, v0);
+                const int su = s[u];
+                const R bw_s = rowsT[6 * kWave + su], c_s = rowsT[6 * kWave + 8 + su];
+                kb[u] = h[u] * rfma(bw_s, lam[u], group_sum8(rowsT[su * kWave + lane] * ZZ[u]));
+                ts[u] = rfma(c_s, h[u], tc[u]);
+                const R al = (ts[u] - t0[u]) * inv_len[u];
+                const R gdv = rfma(al, dd[u], d0[u]);
+                tv[u] = rfma(al, dv[u], v0[u]);
                 R gde = 0.f;
                 if constexpr (GD) gde = gd_effect(o, gdv);
-                // ---- J^T kb: mechanistic part, then the cotangent through the layers; every delta goes to the hand-off slot
                 const R G = lane_bcast(Ys, 0), I = lane_bcast(Ys, 1), Glu = lane_bcast(Ys, 2), GLP1 = lane_bcast(Ys, 3),
                         FFA = lane_bcast(Ys, 5);
-                const R lG = lane_bcast(kb, 0), lI = lane_bcast(kb, 1), lGlu = lane_bcast(kb, 2), lGLP = lane_bcast(kb, 3),
-                        lGE = lane_bcast(kb, 4), lF = lane_bcast(kb, 5);
-                const R mech = mech_vjp<R, GODE>(o, G, I, Glu, GLP1, FFA, lG, lI, lGlu, lGLP, lF, gde, gdv, GD, lane, go);
-                R d = w5[0] * lG;
-                d = rfma(w5[1], lI, d);
-                d = rfma(w5[2], lGlu, d);
-                d = rfma(w5[3], lGLP, d);
-                d = rfma(w5[4], lGE, d);
-                d = rfma(w5[5], lF, d);
-                d = (hact[NL - 1] > 0.f) ? d : 0.f;
-                hd[(NL - 1) * kWave + lane] = d;               // delta_NL
-#pragma unroll
-                for (int l = NL - 1; l >= 1; --l) {            // hidden matrix l-1 maps h_l -> h_{l+1}
-                    const R dp = ws_wt_mul(wt + (size_t)(l - 1) * kMaxH * kMaxH, lane, d);
-                    d = (hact[l - 1] > 0.f) ? dp : 0.f;
-                    hd[(l - 1) * kWave + lane] = d;            // delta_l
-                }
-                if (lane < 8) hd[NL * kWave + lane] = (lane < 6) ? kb : (lane == 6) ? ts : tv;
-                if (lane == 8) reinterpret_cast<int *>(hd + NL * kWave)[8] = 1 + slot;          // valid, and which ring slot
-                R p[6];
-                p[0] = w1[1] * d;
-                p[1] = w1[2] * d;
-                p[2] = w1[3] * d;
-                p[3] = (w1[4] + w1[7]) * d;                    // GLP1 feeds inputs 4 and 7
-                p[4] = w1[5] * d;
-                p[5] = w1[6] * d;
-                const R nnv = wave_reduce6_to_lanes(p, lane);
-                const R Z = (c8 < 6) ? (mech + nnv) : 0.f;
-                ZZ = (grp == s) ? Z : ZZ;
-                if (s == 0) {
-                    lam += group_sum8(rowsT[7 * kWave + lane] * ZZ);
-                    s = S - 1;
-                    if (--st < 0) {
-                        finish_traj();
-                        start_next();
-                    }
-                } else {
-                    --s;
-                }
-            } else {
-                if (lane == 8) reinterpret_cast<int *>(hd + NL * kWave)[8] = 0;
+                const R lG = lane_bcast(kb[u], 0), lI = lane_bcast(kb[u], 1), lGlu = lane_bcast(kb[u], 2), lGLP = lane_bcast(kb[u], 3),
+                        lGE = lane_bcast(kb[u], 4), lF = lane_bcast(kb[u], 5);
+                R gou = 0.f;
+                mech[u] = (dbg & 4) ? kb[u] : mech_vjp<R, GODE>(o, G, I, Glu, GLP1, FFA, lG, lI, lGlu, lGLP, lF, gde, gdv, GD, lane, gou);
+                if constexpr (GODE) go += active[u] ? gou : 0.f;
+                R dl = w5[0] * lG;
+                dl = rfma(w5[1], lI, dl);
+                dl = rfma(w5[2], lGlu, dl);
+                dl = rfma(w5[3], lGLP, dl);
+                dl = rfma(w5[4], lGE, dl);
+                dl = rfma(w5[5], lF, dl);
+                d[u] = (hact[u][NL - 1] > 0.f) ? dl : 0.f;
+                hd[u][(NL - 1) * kWave + lane] = d[u];         // delta_NL
             }
-            __syncthreads();
-        }
-    } else if (isA) {
-        const int m = (wave - kWsP) >> 1, g = (wave - kWsP) & 1;
 #pragma unroll
-        for (int r = 0; r < kMaxH; ++r) gw[r] = 0.f;
-#pragma unroll 1
-        for (int it = 0; it < n_iter; ++it) {
-            if (it > 0 && a.gnn != nullptr) {
-                const int rp = (it - 1) & 1;                   // what the propagation waves published one iteration ago
-#pragma unroll 1
-                for (int q = 0; q < 4; ++q) {
-                    const int pw = 4 * g + q;
-                    const R *__restrict__ hd = hands + ((size_t)pw * 2 + rp) * kHand;
-                    const int tag = first_lane(reinterpret_cast<const int *>(hd + NL * kWave)[8]);
-                    if (tag == 0) continue;
-                    const R *__restrict__ hr = recs + ((size_t)pw * kWsRing + (tag - 1)) * kRec + m * kWave;      // h_m: input of matrix m
-                    float Rh[4];
-                    Rh[0] = hr[p16]; Rh[1] = hr[16 + p16]; Rh[2] = hr[32 + p16]; Rh[3] = hr[48 + p16];
-                    const R d = hd[(m + 1) * kWave + lane];                                                     // delta_{m+1}
-                    asm volatile("" : "+v"(Rh[0]), "+v"(Rh[1]), "+v"(Rh[2]), "+v"(Rh[3]));
-                    mlp_outer_step<0>(gw, d, Rh);
+            for (int l = NL - 1; l >= 1; --l) {                // hidden matrix l-1 maps h_l -> h_{l+1}
+                R dp[U];
+                if (dbg & 2) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) dp[u] = d[u] * 0.5f;
+                } else {
+                    ws_wt_mul(wt + (size_t)(l - 1) * kMaxH * kMaxH, lane, d, dp);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    d[u] = (hact[u][l - 1] > 0.f) ? dp[u] : 0.f;
+                    hd[u][(l - 1) * kWave + lane] = d[u];      // delta_l
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (lane < 8) hd[u][NL * kWave + lane] = (lane < 6) ? kb[u] : (lane == 6) ? ts[u] : tv[u];
+                if (lane == 0) tags[par * 16 + wave * U + u] = active[u] ? 1 + slot[u] : 0;          // valid, and which ring slot
+                R p[6];
+                p[0] = w1[1] * d[u];
+                p[1] = w1[2] * d[u];
+                p[2] = w1[3] * d[u];
+                p[3] = (w1[4] + w1[7]) * d[u];                 // GLP1 feeds inputs 4 and 7
+                p[4] = w1[5] * d[u];
+                p[5] = w1[6] * d[u];
+                const R nnv = (dbg & 8) ? p[0] + p[1] + p[2] + p[3] + p[4] + p[5] : wave_reduce6_to_lanes(p, lane);
+                const R Z = (c8 < 6) ? (mech[u] + nnv) : 0.f;
+                if (active[u]) {
+                    ZZ[u] = (grp == s[u]) ? Z : ZZ[u];
+                    if (s[u] == 0) {
+                        lam[u] += group_sum8(rowsT[7 * kWave + lane] * ZZ[u]);
+                        s[u] = S - 1;
+                        if (--st[u] < 0) {
+                            finish_traj(u);
+                            start_next(u);
+                        }
+                    } else {
+                        --s[u];
+                    }
                 }
             }
             __syncthreads();
         }
     } else {
 #pragma unroll
-        for (int i = 0; i < ES::count; ++i) ge[i] = 0.f;
+        for (int r = 0; r < kMaxH; ++r) gw[r] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 17; ++i) ge[i] = 0.f;
 #pragma unroll 1
         for (int it = 0; it < n_iter; ++it) {
-            if (it > 0 && a.gnn != nullptr) {
-                const int rp = (it - 1) & 1;
+            if (it > 0 && a.gnn != nullptr && !(dbg & 1)) {
+                const int rp = (it - 1) & 1;                   // what the propagation waves published one iteration ago
+                const int mytag = tags[rp * 16 + p16];        // all sixteen tags in one read
+                int tm = 0;                                    // t % an
 #pragma unroll 1
-                for (int pw = 0; pw < kWsP; ++pw) {
-                    const R *__restrict__ hd = hands + ((size_t)pw * 2 + rp) * kHand;
-                    const int tag = first_lane(reinterpret_cast<const int *>(hd + NL * kWave)[8]);
-                    if (tag == 0) continue;
-                    const R *__restrict__ rc = recs + ((size_t)pw * kWsRing + (tag - 1)) * kRec;
-                    const R *__restrict__ xs = rc + NL * kWave, *__restrict__ tl = hd + NL * kWave;         // state | kb[6], t, tvns
-                    const R d1 = hd[lane];
-                    ge[ES::b + 0] += d1;
+                for (int t = 0; t < NT; ++t) {
+                    const int tag = __builtin_amdgcn_readlane(mytag, t);
+                    const bool mine = tm == ar, edge = (aj == 4 + (t & 3));
+                    tm = (tm + 1 == an) ? 0 : tm + 1;
+                    if (tag == 0 || !(mine || edge)) continue;
+                    const R *__restrict__ hd = hands + ((size_t)t * 2 + rp) * kHand;
+                    const R *__restrict__ rc = recs + ((size_t)t * kWsRing + (tag - 1)) * kRec;
+                    if (mine) {
+                        const R *__restrict__ hr = rc + am * kWave;                       // h_m: the input of matrix m
+                        float Rh[4];
+                        Rh[0] = hr[p16]; Rh[1] = hr[16 + p16]; Rh[2] = hr[32 + p16]; Rh[3] = hr[48 + p16];
+                        const R dm = hd[(am + 1) * kWave + lane];                        // delta_{m+1}
+                        asm volatile("" : "+v"(Rh[0]), "+v"(Rh[1]), "+v"(Rh[2]), "+v"(Rh[3]));
+                        mlp_outer_step<0>(gw, dm, Rh);
+                        gb += dm;                                                        // bias of hidden layer m + 2
+                    }
+                    if (edge) {
+                        const R *__restrict__ xs = rc + NL * kWave, *__restrict__ tl = hd + NL * kWave;     // state | kb[6], t, tvns
+                        const R d1 = hd[lane];
+                        // first layer: input row [t, G, I, Glu, GLP1, GE, FFA, glp1 := GLP1, tvns] (broadcast LDS reads)
+                        ge[0] = rfma(d1, tl[6], ge[0]);
+                        ge[1] = rfma(d1, xs[0], ge[1]);
+                        ge[2] = rfma(d1, xs[1], ge[2]);
+                        ge[3] = rfma(d1, xs[2], ge[3]);
+                        ge[4] = rfma(d1, xs[3], ge[4]);
+                        ge[5] = rfma(d1, xs[4], ge[5]);
+                        ge[6] = rfma(d1, xs[5], ge[6]);
+                        ge[7] = rfma(d1, xs[3], ge[7]);
+                        ge[8] = rfma(d1, tl[7], ge[8]);
+                        ge[9] += d1;
+                        // output layer: dWout[q][j] += kb_q h_NL[j], dbout[q] += kb_q
+                        const R hl = rc[(NL - 1) * kWave + lane];
 #pragma unroll
-                    for (int l = 1; l < NL; ++l) ge[ES::b + l] += hd[l * kWave + lane];
-                    // first layer: input row [t, G, I, Glu, GLP1, GE, FFA, glp1 := GLP1, tvns] (broadcast LDS reads)
-                    ge[ES::w1 + 0] = rfma(d1, tl[6], ge[ES::w1 + 0]);
-                    ge[ES::w1 + 1] = rfma(d1, xs[0], ge[ES::w1 + 1]);
-                    ge[ES::w1 + 2] = rfma(d1, xs[1], ge[ES::w1 + 2]);
-                    ge[ES::w1 + 3] = rfma(d1, xs[2], ge[ES::w1 + 3]);
-                    ge[ES::w1 + 4] = rfma(d1, xs[3], ge[ES::w1 + 4]);
-                    ge[ES::w1 + 5] = rfma(d1, xs[4], ge[ES::w1 + 5]);
-                    ge[ES::w1 + 6] = rfma(d1, xs[5], ge[ES::w1 + 6]);
-                    ge[ES::w1 + 7] = rfma(d1, xs[3], ge[ES::w1 + 7]);
-                    ge[ES::w1 + 8] = rfma(d1, tl[7], ge[ES::w1 + 8]);
-                    // output layer: dWout[q][j] += kb_q h_NL[j], dbout[q] += kb_q
-                    const R hl = rc[(NL - 1) * kWave + lane];
-#pragma unroll
-                    for (int q = 0; q < 6; ++q) ge[ES::w5 + q] = rfma(tl[q], hl, ge[ES::w5 + q]);
-                    ge[ES::b5] += tl[c8];                      // lanes 0..5 hold dbout (slots 6, 7 carry t / tVNS: never stored)
+                        for (int q = 0; q < 6; ++q) ge[10 + q] = rfma(tl[q], hl, ge[10 + q]);
+                        ge[16] += tl[c8];                      // lanes 0..5 hold dbout (slots 6, 7 carry t / tVNS: never stored)
+                    }
                 }
             }
             __syncthreads();
         }
     }
 
-    // ---- epilogue: ONE gradient row per workgroup (see the header; same row format as solve_bwd_kernel) -----------------------
-    const int nthreads = 64 * kWaves;
+    // ---- epilogue: ONE gradient row per workgroup (same row format as solve_bwd_kernel); every sum in a fixed order ------------
+    const int nthreads = 64 * kWsWaves;
     const size_t rowlen = adj_partial_rowlen(a.P);
     R *__restrict__ prow = a.partials + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * rowlen;
     const int H = a.H;
     if (a.gnn) {
-        constexpr int kHid = (NL - 1) * kMaxH * kMaxH;
-        // the image of the transposed matrices is dead: it becomes the [matrix][row][col] sum of the two accumulation groups
-        for (int g = 0; g < 2; ++g) {
-            if (isA && ((wave - kWsP) & 1) == g) {
-                const int m = (wave - kWsP) >> 1;
+        constexpr int kHid = NM * kMaxH * kMaxH;
+        // the image of the transposed matrices is dead: it becomes the [matrix][row][col] sum over the waves of each matrix
+        for (int rr = 0; rr < kMaxRank; ++rr) {
+            if (!isP && ar == rr) {
 #pragma unroll
                 for (int r = 0; r < kMaxH; ++r) {
-                    R *dst = wt + (size_t)m * kMaxH * kMaxH + lane * kMaxH + wcol<R>(r, lane);
-                    *dst = (g == 0) ? gw[r] : *dst + gw[r];
+                    R *dst = wt + (size_t)am * kMaxH * kMaxH + lane * kMaxH + wcol<R>(r, lane);
+                    *dst = (rr == 0) ? gw[r] : *dst + gw[r];
                 }
             }
             __syncthreads();
@@ -420,16 +499,34 @@ __global__ __launch_bounds__(64 * ws_waves<NL>()) void solve_bwd_ws_kernel(const
             const int l = i >> 12, row = (i >> 6) & 63, col = i & 63;
             if (row < H && col < H) prow[9 * H + H + (size_t)l * ((size_t)H * H + H) + (size_t)row * H + col] = wt[i];
         }
-        if (!isP && !isA && lane < H) {
-            const size_t off_out = (size_t)9 * H + H + (size_t)(NL - 1) * ((size_t)H * H + H);
+        // biases and edge layers: [slot][64] in the (dead) record area, wave after wave
+        R *edgeS = recs;
+        for (int i = threadIdx.x; i < ES::count * kWave; i += nthreads) edgeS[i] = 0.f;
+        __syncthreads();
+        for (int jj = 0; jj < kWsA; ++jj) {
+            if (aj == jj) {
+                edgeS[(ES::b + am + 1) * kWave + lane] += gb;
+                if (jj >= 4) {
 #pragma unroll
-            for (int i = 0; i < 9; ++i) prow[lane * 9 + i] = ge[ES::w1 + i];
-            prow[9 * H + lane] = ge[ES::b + 0];
+                    for (int i = 0; i < 9; ++i) edgeS[(ES::w1 + i) * kWave + lane] += ge[i];
+                    edgeS[(ES::b + 0) * kWave + lane] += ge[9];
 #pragma unroll
-            for (int l = 1; l < NL; ++l) prow[9 * H + H + (size_t)(l - 1) * ((size_t)H * H + H) + (size_t)H * H + lane] = ge[ES::b + l];
-#pragma unroll
-            for (int q = 0; q < 6; ++q) prow[off_out + q * H + lane] = ge[ES::w5 + q];
-            if (lane < 6) prow[off_out + 6 * H + lane] = ge[ES::b5];
+                    for (int q = 0; q < 6; ++q) edgeS[(ES::w5 + q) * kWave + lane] += ge[10 + q];
+                    edgeS[ES::b5 * kWave + lane] += ge[16];
+                }
+            }
+            __syncthreads();
+        }
+        const size_t off_out = (size_t)9 * H + H + (size_t)NM * ((size_t)H * H + H);
+        for (int i = threadIdx.x; i < ES::count * kWave; i += nthreads) {
+            const int slot = i >> 6, j = i & 63;
+            const R v = edgeS[i];
+            if (slot < ES::b) { if (j < H) prow[j * 9 + slot] = v; }
+            else if (slot < ES::w5) {
+                const int l = slot - ES::b;
+                if (j < H) prow[9 * H + (l == 0 ? 0 : H + (size_t)(l - 1) * ((size_t)H * H + H) + (size_t)H * H) + j] = v;
+            } else if (slot < ES::b5) { if (j < H) prow[off_out + (slot - ES::w5) * H + j] = v; }
+            else if (j < 6) prow[off_out + 6 * H + j] = v;
         }
     }
     if constexpr (GODE) {
@@ -446,20 +543,33 @@ __global__ __launch_bounds__(64 * ws_waves<NL>()) void solve_bwd_ws_kernel(const
     }
 }
 
-template <int NL, bool GODE, bool GD> static int launch_ws_g(hipStream_t s, const AdjArgs<float> &a, int method, int cus)
+template <int NL, int U, bool GODE, bool GD> static int launch_ws_u(hipStream_t s, const AdjArgs<float> &a, int method, int blocks)
 {
-    const int per_set = a.B / a.n_sets;
-    int blocks = per_set < cus ? per_set : cus;           // one workgroup per CU; its propagation waves loop over trajectories
-    if (a.n_sets > 1 && blocks * a.n_sets > cus) blocks = cus / a.n_sets;
-    if (blocks < 1) blocks = 1;
-    if (a.partials == nullptr || blocks * a.n_sets > a.partial_rows) return HODE_EUNSUPPORTED;     // caller falls back
-    const size_t lds = ws_lds_elems<NL>() * sizeof(float);
-    auto kern = solve_bwd_ws_kernel<NL, GODE, GD>;
+    const size_t lds = ws_lds_elems<NL, U>() * sizeof(float);
+    auto kern = solve_bwd_ws_kernel<NL, U, GODE, GD>;
     if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return HODE_ELAUNCH;
-    hipLaunchKernelGGL(kern, dim3(blocks, a.n_sets), dim3(64 * ws_waves<NL>()), lds, s, a, method);
+    hipLaunchKernelGGL(kern, dim3(blocks, a.n_sets), dim3(64 * kWsWaves), lds, s, a, method);
     if (a.gnn || (GODE && a.gode))
         launch_adj_reduce(s, a.partials, (int)adj_partial_rowlen(a.P), blocks, a.n_sets, a.P, a.gnn, GODE ? a.gode : nullptr);
     return hipGetLastError() == hipSuccess ? HODE_OK : HODE_ELAUNCH;
+}
+
+template <int NL, bool GODE, bool GD> static int launch_ws_g(hipStream_t s, const AdjArgs<float> &a, int method, int cus)
+{
+    const int per_set = a.B / a.n_sets;
+    int blocks = per_set < cus ? per_set : cus;           // one workgroup per CU; its trajectory slots loop over trajectories
+    if (a.n_sets > 1 && blocks * a.n_sets > cus) blocks = cus / a.n_sets;
+    if (blocks < 1) blocks = 1;
+    if (a.partials == nullptr || blocks * a.n_sets > a.partial_rows) return HODE_EUNSUPPORTED;     // caller falls back
+    // two trajectories per propagation wave as soon as a workgroup has more than eight to process
+    int two = per_set > blocks * kWsP;
+#ifdef HODE_LAB
+    static const int dbg = [] { const char *e = getenv("HODE_WS_DBG"); return e ? atoi(e) : 0; }();
+    method |= (dbg & 0xff) << 8;
+    if (dbg & 256) two = 0;
+    if (dbg & 512) two = 1;
+#endif
+    return two ? launch_ws_u<NL, 2, GODE, GD>(s, a, method, blocks) : launch_ws_u<NL, 1, GODE, GD>(s, a, method, blocks);
 }
 
 template <int NL> static int launch_ws_nl(hipStream_t s, const AdjArgs<float> &a, int method, int cus)
