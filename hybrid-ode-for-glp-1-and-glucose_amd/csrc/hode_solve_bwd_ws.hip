@@ -41,7 +41,7 @@ constexpr int kWsA = 8;                                    // accumulation waves
 constexpr int kWsWaves = kWsP + kWsA;
 constexpr int kWsRing = 3;                                 // record ring: being DMA'd | being propagated | being accumulated
 template <int NL> constexpr int ws_rec_elems() { return (NL + 1) * kWave; }          // NL rows + the stage state (8 of 64 used)
-template <int NL> constexpr int ws_hand_elems() { return NL * kWave + 16; }          // delta_1..delta_NL + {kb[6], t, tvns}
+template <int NL> constexpr int ws_hand_elems() { return (NL + 1) * kWave; }         // delta_1..delta_NL + {kb[6], t, tvns} x 8
 template <int NL, int U> constexpr size_t ws_lds_elems()
 {
     return (size_t)(NL - 1) * kMaxH * kMaxH + 8 * kWave + (size_t)kWsP * U * kWsRing * ws_rec_elems<NL>() +
@@ -52,6 +52,32 @@ __device__ __forceinline__ float inp_at_w(const float *__restrict__ p, int mode,
 {
     if (mode == 0) return 0.f;
     return (mode == 1) ? p[b] : p[(size_t)b * T + k];
+}
+
+// J_mech^T kb as mech_vjp (hode_device.h) computes it, with the five terms evaluated on ALL lanes and selected by lane -- the
+// propagation waves have the registers for it, and the exec-masked regions hipcc builds out of a nested ?: cost a
+// v_cmp / s_and_saveexec / s_cbranch_execz round trip per term on a wave whose time is its instruction count
+template <bool GODE>
+__device__ __forceinline__ float ws_mech_vjp(const OdeP<float> &o, float G, float I, float Glu, float GLP1, float FFA, float lG, float lI,
+                                             float lGlu, float lGLP, float lF, float gde, float gd_in, bool use_gd, int lane, float &go)
+{
+    if constexpr (GODE) return mech_vjp<float, true>(o, G, I, Glu, GLP1, FFA, lG, lI, lGlu, lGLP, lF, gde, gd_in, use_gd, lane, go);
+    const float Pi = 1.f + o.rho * GLP1;
+    const float den1 = o.EC_50 + GLP1, den2 = o.K_m + G;
+    const float k_GE = o.k_GE0 * (1.f - gde);
+    const float r1 = rdiv(1.f, den1), r2 = rdiv(1.f, den2);
+    const float oG = -k_GE * lG + Pi * o.a_GI * lI + o.V_max * o.K_m * r2 * r2 * lGLP + o.p_9 * FFA * lF;
+    const float oI = -0.01f * lG - o.k_I * lI - o.p_8 * FFA * lF;
+    const float oGlu = 0.005f * lG - o.E_max * GLP1 * r1 * lGlu;
+    const float oGLP = o.rho * o.a_GI * (G - o.G_b) * lI - o.E_max * o.EC_50 * r1 * r1 * (Glu - o.Glu_b) * lGlu - o.k_L * lGLP;
+    const float oF = (-o.p_7 - o.p_8 * I + o.p_9 * G) * lF;
+    const int c8 = lane & 7;
+    float r = keep_term(c8 == 0, oG, 0.f);
+    r = keep_term(c8 == 1, oI, r);
+    r = keep_term(c8 == 2, oGlu, r);
+    r = keep_term(c8 == 3, oGLP, r);
+    r = keep_term(c8 == 5, oF, r);
+    return r;
 }
 
 // delta_prev = W^T delta from the LDS image (hode_device.h: wt_rot_store), reads issued two groups of four ahead of their use:
@@ -188,6 +214,11 @@ __global__ __launch_bounds__(64 * kWsWaves) void solve_bwd_ws_kernel(const AdjAr
     const int S = kTableau[method].S;
     const R *__restrict__ nn_set = a.nn_p + (size_t)set * a.P;
     const bool isP = wave < kWsP;
+    // restrict-qualified views: wave-uniform reads of them are scalar loads (through the struct members hipcc has to assume
+    // they alias the gx0 stores and falls back to exec-masked vector loads with a full vmcnt wait each)
+    const R *__restrict__ const gy_ = a.gy, *__restrict__ const tgrid_ = a.t, *__restrict__ const tape_ = a.tape,
+                        *__restrict__ const tvns_ = a.tvns, *__restrict__ const gd_ = a.gd, *__restrict__ const stage_ = a.tape_stage;
+    const int *__restrict__ const seg_ = a.tape_seg, *__restrict__ const nsteps_ = a.nsteps, *__restrict__ const status_ = a.status;
 
     wt_rot_store<R>(wt, nn_set, a.H, NM, threadIdx.x, 64 * kWsWaves);
     tableau_rowsT_store<R>(rowsT, method, threadIdx.x, 64 * kWsWaves);
@@ -202,7 +233,7 @@ __global__ __launch_bounds__(64 * kWsWaves) void solve_bwd_ws_kernel(const AdjAr
         for (int u = 0; u < U; ++u) {
             int tot = 0;
             for (int bi = (wave * U + u) * gridDim.x + blockIdx.x; bi < per_set; bi += gridDim.x * NT) {
-                const int nb = a.nsteps[set * per_set + bi];
+                const int nb = nsteps_[set * per_set + bi];
                 tot += (nb < a.max_steps ? nb : a.max_steps) * S;
             }
             mx = tot > mx ? tot : mx;
@@ -238,24 +269,34 @@ __global__ __launch_bounds__(64 * kWsWaves) void solve_bwd_ws_kernel(const AdjAr
 #pragma unroll
             for (int q = 0; q < 6; ++q) w5[q] = live * pout[q * a.H + j];
             ode_load(o, a.ode_p + 17 * set);
+            // as VGPRs: 17 wave-uniform SGPRs are more than this loop has (they were spilled to lanes of a VGPR and read back with
+            // a v_readlane per use), and a VALU instruction reads one SGPR only -- the state / cotangent broadcasts are SGPRs already
+            asm volatile("" : "+v"(o.a_GI), "+v"(o.k_I), "+v"(o.rho), "+v"(o.G_b), "+v"(o.I_b), "+v"(o.E_max), "+v"(o.EC_50), "+v"(o.Glu_b));
+            asm volatile("" : "+v"(o.V_max), "+v"(o.K_m), "+v"(o.k_L), "+v"(o.k_GE0), "+v"(o.IGD_50), "+v"(o.g), "+v"(o.p_7), "+v"(o.p_8), "+v"(o.p_9));
         }
         auto rec_of = [&](int u) -> R * { return recs + (size_t)(wave * U + u) * kWsRing * kRec; };
         auto hand_of = [&](int u, int par) -> R * { return hands + ((size_t)(wave * U + u) * 2 + par) * kHand; };
+        // one record = NL rows of 64 reals + the stage state: NL + 1 DMA instructions off ONE address pair, the row offset is the
+        // instruction's immediate (it advances the global and the LDS address alike).  The last row is loaded whole although
+        // only 8 reals of it belong to the record: the other 56 are the head of the next record (or, behind the very last one,
+        // of the gradient rows that follow the stage tape): read, never used -- and no exec mask to set up
         auto rec_dma = [&](const R *__restrict__ src, R *dst) {
-#pragma unroll
-            for (int l = 0; l < NL; ++l)
-                __builtin_amdgcn_global_load_lds(src + l * kWave + lane, (__attribute__((address_space(3))) void *)(dst + l * kWave), 4, 0, 0);
-            if (lane < 8)
-                __builtin_amdgcn_global_load_lds(src + NL * kWave + lane, (__attribute__((address_space(3))) void *)(dst + NL * kWave), 4, 0, 0);
+            const R *gsrc = src + lane;
+            auto ldst = (__attribute__((address_space(3))) void *)dst;
+            __builtin_amdgcn_global_load_lds(gsrc, ldst, 4, 0, 0);
+            if constexpr (NL >= 1) __builtin_amdgcn_global_load_lds(gsrc, ldst, 4, 256, 0);
+            if constexpr (NL >= 2) __builtin_amdgcn_global_load_lds(gsrc, ldst, 4, 512, 0);
+            if constexpr (NL >= 3) __builtin_amdgcn_global_load_lds(gsrc, ldst, 4, 768, 0);
+            if constexpr (NL >= 4) __builtin_amdgcn_global_load_lds(gsrc, ldst, 4, 1024, 0);
         };
         auto inject = [&](int u, int r) {              // lam += dLoss/dy[b, r, :]  (six wave-uniform scalar loads)
-            const R *__restrict__ gr = a.gy + ((size_t)b[u] * T + r) * 6;
+            const R *__restrict__ gr = gy_ + ((size_t)b[u] * T + r) * 6;
             const R g0 = gr[0], g1 = gr[1], g2 = gr[2], g3 = gr[3], g4 = gr[4], g5 = gr[5];
             lam[u] += (c8 == 0) ? g0 : (c8 == 1) ? g1 : (c8 == 2) ? g2 : (c8 == 3) ? g3 : (c8 == 4) ? g4 : (c8 == 5) ? g5 : 0.f;
         };
         // rows 0..kf of a trajectory are (copies of) x0: their cotangents close the trajectory (see solve_bwd_kernel)
         auto finish_traj = [&](int u) {
-            const R *__restrict__ tg = a.t + (a.t_batched ? (size_t)b[u] * T : 0);
+            const R *__restrict__ tg = tgrid_ + (a.t_batched ? (size_t)b[u] * T : 0);
             int kf = 0;
             while (kf + 1 < T && !(tg[kf + 1] > tg[kf])) ++kf;
             for (int r = 0; r <= kf; ++r) inject(u, r);
@@ -267,9 +308,9 @@ __global__ __launch_bounds__(64 * kWsWaves) void solve_bwd_ws_kernel(const AdjAr
             while (bi_next[u] < per_set) {
                 b[u] = set * per_set + bi_next[u];
                 bi_next[u] += gridDim.x * NT;
-                stg[u] = a.tape_stage + (size_t)b[u] * a.max_steps * 6 * kSlot;
-                n[u] = a.nsteps[b[u]] < a.max_steps ? a.nsteps[b[u]] : a.max_steps;      // never walk past the tape
-                ok[u] = a.status[b[u]] == HODE_ST_OK;
+                stg[u] = stage_ + (size_t)b[u] * a.max_steps * 6 * kSlot;
+                n[u] = nsteps_[b[u]] < a.max_steps ? nsteps_[b[u]] : a.max_steps;      // never walk past the tape
+                ok[u] = status_[b[u]] == HODE_ST_OK;
                 lam[u] = 0.f;
                 knext[u] = T - 1;
                 if (n[u] > 0) {
@@ -287,7 +328,7 @@ __global__ __launch_bounds__(64 * kWsWaves) void solve_bwd_ws_kernel(const AdjAr
             bi_next[u] = (wave * U + u) * gridDim.x + blockIdx.x;
             cur[u] = 0; st[u] = -1; s[u] = 0; k[u] = 0; n[u] = 0; b[u] = 0; knext[u] = 0; ok[u] = true;
             lam[u] = ZZ[u] = tc[u] = h[u] = t0[u] = inv_len[u] = v0[u] = dv[u] = d0[u] = dd[u] = 0.f;
-            stg[u] = a.tape_stage;
+            stg[u] = stage_;
             start_next(u);
         }
 #pragma unroll 1
@@ -297,9 +338,9 @@ __global__ __launch_bounds__(64 * kWsWaves) void solve_bwd_ws_kernel(const AdjAr
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 if (active[u] && s[u] == S - 1) {
-                    const R *__restrict__ tg = a.t + (a.t_batched ? (size_t)b[u] * T : 0);
-                    const R *__restrict__ tape = a.tape + (size_t)b[u] * a.max_steps * 8;
-                    const int kraw = a.tape_seg[(size_t)b[u] * a.max_steps + st[u]];
+                    const R *__restrict__ tg = tgrid_ + (a.t_batched ? (size_t)b[u] * T : 0);
+                    const R *__restrict__ tape = tape_ + (size_t)b[u] * a.max_steps * 8;
+                    const int kraw = seg_[(size_t)b[u] * a.max_steps + st[u]];
                     k[u] = kraw & (kSegClosed - 1);
                     int hi = knext[u];
                     if (st[u] == n[u] - 1) {
@@ -318,10 +359,10 @@ __global__ __launch_bounds__(64 * kWsWaves) void solve_bwd_ws_kernel(const AdjAr
                     h[u] = tape[(size_t)st[u] * 8 + 1];
                     t0[u] = tg[k[u]];
                     const R t1 = tg[k[u] + 1];
-                    v0[u] = inp_at_w(a.tvns, a.tvns_mode, b[u], T, k[u]);
-                    const R v1 = inp_at_w(a.tvns, a.tvns_mode, b[u], T, k[u] + 1);
-                    d0[u] = inp_at_w(a.gd, a.gd_mode, b[u], T, k[u]);
-                    const R d1 = inp_at_w(a.gd, a.gd_mode, b[u], T, k[u] + 1);
+                    v0[u] = inp_at_w(tvns_, a.tvns_mode, b[u], T, k[u]);
+                    const R v1 = inp_at_w(tvns_, a.tvns_mode, b[u], T, k[u] + 1);
+                    d0[u] = inp_at_w(gd_, a.gd_mode, b[u], T, k[u]);
+                    const R d1 = inp_at_w(gd_, a.gd_mode, b[u], T, k[u] + 1);
                     inv_len[u] = first_lane(1.f / (t1 - t0[u]));
                     dv[u] = first_lane(v1 - v0[u]);
                     dd[u] = first_lane(d1 - d0[u]);
@@ -368,7 +409,7 @@ __global__ __launch_bounds__(64 * kWsWaves) void solve_bwd_ws_kernel(const AdjAr
                 const R lG = lane_bcast(kb[u], 0), lI = lane_bcast(kb[u], 1), lGlu = lane_bcast(kb[u], 2), lGLP = lane_bcast(kb[u], 3),
                         lGE = lane_bcast(kb[u], 4), lF = lane_bcast(kb[u], 5);
                 R gou = 0.f;
-                mech[u] = (dbg & 4) ? kb[u] : mech_vjp<R, GODE>(o, G, I, Glu, GLP1, FFA, lG, lI, lGlu, lGLP, lF, gde, gdv, GD, lane, gou);
+                mech[u] = (dbg & 4) ? kb[u] : ws_mech_vjp<GODE>(o, G, I, Glu, GLP1, FFA, lG, lI, lGlu, lGLP, lF, gde, gdv, GD, lane, gou);
                 if constexpr (GODE) go += active[u] ? gou : 0.f;
                 R dl = w5[0] * lG;
                 dl = rfma(w5[1], lI, dl);
@@ -396,8 +437,9 @@ __global__ __launch_bounds__(64 * kWsWaves) void solve_bwd_ws_kernel(const AdjAr
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                if (lane < 8) hd[u][NL * kWave + lane] = (lane < 6) ? kb[u] : (lane == 6) ? ts[u] : tv[u];
-                if (lane == 0) tags[par * 16 + wave * U + u] = active[u] ? 1 + slot[u] : 0;          // valid, and which ring slot
+                // lanes 0..5 kb, 6 t, 7 tVNS (the other groups of eight: copies, never read): no exec mask.  The tag: every lane writes the same word
+                hd[u][NL * kWave + lane] = (c8 < 6) ? kb[u] : (c8 == 6) ? ts[u] : tv[u];
+                tags[par * 16 + wave * U + u] = active[u] ? 1 + slot[u] : 0;                      // valid, and which ring slot
                 R p[6];
                 p[0] = w1[1] * d[u];
                 p[1] = w1[2] * d[u];
