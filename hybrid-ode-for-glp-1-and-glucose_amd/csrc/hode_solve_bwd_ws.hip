@@ -177,6 +177,74 @@ __device__ __forceinline__ void ws_wt_mul(const float *__restrict__ wt, int lane
 
 }  // namespace
 
+// Accumulation wave AJ: matrix AJ % (NL-1), rank AJ / (NL-1) among that matrix's waves; slot t belongs to the wave of rank
+// t % (waves of the matrix); waves 4..7 also keep the first / last layer gradients of the slots t with t % 4 == AJ - 4.
+// One slot (compile-time t: every LDS address is a base register + an immediate), then the next one.
+template <int NL, int U, int AJ, int T0>
+__device__ __forceinline__ void ws_acc_slot(const float *__restrict__ recs, const float *__restrict__ hbase, const int mytag, const int lane,
+                                            float (&gw)[kMaxH], float &gb, float (&ge)[17])
+{
+    constexpr int NM = NL - 1, NT = kWsP * U;
+    constexpr int am = AJ % NM, ar = AJ / NM, an = (kWsA - 1 - am) / NM + 1;
+    constexpr int kRec = ws_rec_elems<NL>(), kHand = ws_hand_elems<NL>();
+    if constexpr (T0 < NT) {
+        constexpr bool mine = (T0 % an) == ar, edge = AJ >= 4 && (T0 & 3) == AJ - 4;
+        if constexpr (mine || edge) {
+            const int tag = __builtin_amdgcn_readlane(mytag, T0);
+            if (tag != 0) {
+                const float *__restrict__ hd = hbase + (size_t)T0 * 2 * kHand;
+                const float *__restrict__ rc = recs + ((size_t)T0 * kWsRing + (tag - 1)) * kRec;
+                if constexpr (mine) {
+                    const int p16 = lane & 15;
+                    const float *__restrict__ hr = rc + am * kWave;                       // h_m: the input of matrix m
+                    float Rh[4];
+                    Rh[0] = hr[p16]; Rh[1] = hr[16 + p16]; Rh[2] = hr[32 + p16]; Rh[3] = hr[48 + p16];
+                    const float dm = hd[(am + 1) * kWave + lane];                        // delta_{m+1}
+                    asm volatile("" : "+v"(Rh[0]), "+v"(Rh[1]), "+v"(Rh[2]), "+v"(Rh[3]));
+                    mlp_outer_step<0>(gw, dm, Rh);
+                    gb += dm;                                                            // bias of hidden layer m + 2
+                }
+                if constexpr (edge) {
+                    const float *__restrict__ xs = rc + NL * kWave, *__restrict__ tl = hd + NL * kWave;     // state | kb[6], t, tvns
+                    const float d1 = hd[lane];
+                    // first layer: input row [t, G, I, Glu, GLP1, GE, FFA, glp1 := GLP1, tvns] (broadcast LDS reads)
+                    ge[0] = rfma(d1, tl[6], ge[0]);
+                    ge[1] = rfma(d1, xs[0], ge[1]);
+                    ge[2] = rfma(d1, xs[1], ge[2]);
+                    ge[3] = rfma(d1, xs[2], ge[3]);
+                    ge[4] = rfma(d1, xs[3], ge[4]);
+                    ge[5] = rfma(d1, xs[4], ge[5]);
+                    ge[6] = rfma(d1, xs[5], ge[6]);
+                    ge[7] = rfma(d1, xs[3], ge[7]);
+                    ge[8] = rfma(d1, tl[7], ge[8]);
+                    ge[9] += d1;
+                    // output layer: dWout[q][j] += kb_q h_NL[j], dbout[q] += kb_q
+                    const float hl = rc[(NL - 1) * kWave + lane];
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) ge[10 + q] = rfma(tl[q], hl, ge[10 + q]);
+                    ge[16] += tl[lane & 7];                    // lanes 0..5 hold dbout (slots 6, 7 carry t / tVNS: never stored)
+                }
+            }
+        }
+        ws_acc_slot<NL, U, AJ, T0 + 1>(recs, hbase, mytag, lane, gw, gb, ge);
+    }
+}
+template <int NL, int U, int AJ>
+__device__ __forceinline__ void ws_acc_loop(const float *__restrict__ recs, const float *__restrict__ hands, const int *__restrict__ tags,
+                                            const int n_iter, const bool work, const int lane, float (&gw)[kMaxH], float &gb, float (&ge)[17])
+{
+    constexpr int kHand = ws_hand_elems<NL>();
+#pragma unroll 1
+    for (int it = 0; it < n_iter; ++it) {
+        if (it > 0 && work) {
+            const int rp = (it - 1) & 1;                       // what the propagation waves published one iteration ago
+            const int mytag = tags[rp * 16 + (lane & 15)];    // all sixteen tags in one read
+            ws_acc_slot<NL, U, AJ, 0>(recs, hands + rp * kHand, mytag, lane, gw, gb, ge);
+        }
+        __syncthreads();
+    }
+}
+
 template <int NL, int U, bool GODE, bool GD>
 __global__ __launch_bounds__(64 * kWsWaves) void solve_bwd_ws_kernel(const AdjArgs<float> a, const int method_dbg)
 {
@@ -199,7 +267,7 @@ __global__ __launch_bounds__(64 * kWsWaves) void solve_bwd_ws_kernel(const AdjAr
     int *niter = tags + 2 * 16;
 
     const int lane = threadIdx.x & 63;
-    const int c8 = lane & 7, grp = lane >> 3, p16 = lane & 15;
+    const int c8 = lane & 7, grp = lane >> 3;
     const int wave = first_lane((int)(threadIdx.x >> 6));
     const int set = blockIdx.y;
     const int T = a.T;
@@ -251,7 +319,6 @@ __global__ __launch_bounds__(64 * kWsWaves) void solve_bwd_ws_kernel(const AdjAr
     R go = 0.f;                                           // P: lane p < 17 holds d/d(ode constant p)
     const int aj = wave - kWsP;                           // accumulation wave index
     const int am = aj % NM, ar = aj / NM;                 // its matrix and its rank among that matrix's waves
-    const int an = (kWsA - 1 - am) / NM + 1;              // accumulation waves of matrix am
     if (isP) {
         // edge weights in registers (no accumulators here: there is room); per trajectory: step / stage cursors
         R w1[9], w5[6];
@@ -470,52 +537,18 @@ __global__ __launch_bounds__(64 * kWsWaves) void solve_bwd_ws_kernel(const AdjAr
         for (int r = 0; r < kMaxH; ++r) gw[r] = 0.f;
 #pragma unroll
         for (int i = 0; i < 17; ++i) ge[i] = 0.f;
-#pragma unroll 1
-        for (int it = 0; it < n_iter; ++it) {
-            if (it > 0 && a.gnn != nullptr && !(dbg & 1)) {
-                const int rp = (it - 1) & 1;                   // what the propagation waves published one iteration ago
-                const int mytag = tags[rp * 16 + p16];        // all sixteen tags in one read
-                int tm = 0;                                    // t % an
-#pragma unroll 1
-                for (int t = 0; t < NT; ++t) {
-                    const int tag = __builtin_amdgcn_readlane(mytag, t);
-                    const bool mine = tm == ar, edge = (aj == 4 + (t & 3));
-                    tm = (tm + 1 == an) ? 0 : tm + 1;
-                    if (tag == 0 || !(mine || edge)) continue;
-                    const R *__restrict__ hd = hands + ((size_t)t * 2 + rp) * kHand;
-                    const R *__restrict__ rc = recs + ((size_t)t * kWsRing + (tag - 1)) * kRec;
-                    if (mine) {
-                        const R *__restrict__ hr = rc + am * kWave;                       // h_m: the input of matrix m
-                        float Rh[4];
-                        Rh[0] = hr[p16]; Rh[1] = hr[16 + p16]; Rh[2] = hr[32 + p16]; Rh[3] = hr[48 + p16];
-                        const R dm = hd[(am + 1) * kWave + lane];                        // delta_{m+1}
-                        asm volatile("" : "+v"(Rh[0]), "+v"(Rh[1]), "+v"(Rh[2]), "+v"(Rh[3]));
-                        mlp_outer_step<0>(gw, dm, Rh);
-                        gb += dm;                                                        // bias of hidden layer m + 2
-                    }
-                    if (edge) {
-                        const R *__restrict__ xs = rc + NL * kWave, *__restrict__ tl = hd + NL * kWave;     // state | kb[6], t, tvns
-                        const R d1 = hd[lane];
-                        // first layer: input row [t, G, I, Glu, GLP1, GE, FFA, glp1 := GLP1, tvns] (broadcast LDS reads)
-                        ge[0] = rfma(d1, tl[6], ge[0]);
-                        ge[1] = rfma(d1, xs[0], ge[1]);
-                        ge[2] = rfma(d1, xs[1], ge[2]);
-                        ge[3] = rfma(d1, xs[2], ge[3]);
-                        ge[4] = rfma(d1, xs[3], ge[4]);
-                        ge[5] = rfma(d1, xs[4], ge[5]);
-                        ge[6] = rfma(d1, xs[5], ge[6]);
-                        ge[7] = rfma(d1, xs[3], ge[7]);
-                        ge[8] = rfma(d1, tl[7], ge[8]);
-                        ge[9] += d1;
-                        // output layer: dWout[q][j] += kb_q h_NL[j], dbout[q] += kb_q
-                        const R hl = rc[(NL - 1) * kWave + lane];
-#pragma unroll
-                        for (int q = 0; q < 6; ++q) ge[10 + q] = rfma(tl[q], hl, ge[10 + q]);
-                        ge[16] += tl[c8];                      // lanes 0..5 hold dbout (slots 6, 7 carry t / tVNS: never stored)
-                    }
-                }
-            }
-            __syncthreads();
+        // one instantiation per accumulation wave: which slots it serves is a compile-time table, every LDS address below is a
+        // base register + an immediate
+        const bool work = a.gnn != nullptr && !(dbg & 1);
+        switch (aj) {
+        case 0: ws_acc_loop<NL, U, 0>(recs, hands, tags, n_iter, work, lane, gw, gb, ge); break;
+        case 1: ws_acc_loop<NL, U, 1>(recs, hands, tags, n_iter, work, lane, gw, gb, ge); break;
+        case 2: ws_acc_loop<NL, U, 2>(recs, hands, tags, n_iter, work, lane, gw, gb, ge); break;
+        case 3: ws_acc_loop<NL, U, 3>(recs, hands, tags, n_iter, work, lane, gw, gb, ge); break;
+        case 4: ws_acc_loop<NL, U, 4>(recs, hands, tags, n_iter, work, lane, gw, gb, ge); break;
+        case 5: ws_acc_loop<NL, U, 5>(recs, hands, tags, n_iter, work, lane, gw, gb, ge); break;
+        case 6: ws_acc_loop<NL, U, 6>(recs, hands, tags, n_iter, work, lane, gw, gb, ge); break;
+        default: ws_acc_loop<NL, U, 7>(recs, hands, tags, n_iter, work, lane, gw, gb, ge); break;
         }
     }
 
