@@ -85,11 +85,7 @@ __device__ __forceinline__ float ws_mech_vjp(const OdeP<float> &o, float G, floa
 template <int G> __device__ __forceinline__ void ws_wt_group(const Vec4<float> (&w)[4], const float (&Rd)[4], float (&acc)[4])
 {
     static_assert(G >= 0 && G < 4, "four groups of sixteen rotations");
-#define HODE_WS_FM(OP0, a0s)                                                                                                   \
-    asm(OP0 " %[a0], %[r], %[w0]" a0s "\n\t"                                                                                   \
-        "v_fmac_f32_dpp %[a1], %[r], %[w1] row_ror:1 row_mask:0xf bank_mask:0xf\n\t"                                           \
-        "v_fmac_f32_dpp %[a2], %[r], %[w2] row_ror:2 row_mask:0xf bank_mask:0xf\n\t"                                           \
-        "v_fmac_f32_dpp %[a3], %[r], %[w3] row_ror:3 row_mask:0xf bank_mask:0xf\n\t"                                           \
+#define HODE_WS_TAIL                                                                                                            \
         "v_fmac_f32_dpp %[a0], %[r], %[w4] row_ror:4 row_mask:0xf bank_mask:0xf\n\t"                                           \
         "v_fmac_f32_dpp %[a1], %[r], %[w5] row_ror:5 row_mask:0xf bank_mask:0xf\n\t"                                           \
         "v_fmac_f32_dpp %[a2], %[r], %[w6] row_ror:6 row_mask:0xf bank_mask:0xf\n\t"                                           \
@@ -101,14 +97,30 @@ template <int G> __device__ __forceinline__ void ws_wt_group(const Vec4<float> (
         "v_fmac_f32_dpp %[a0], %[r], %[w12] row_ror:12 row_mask:0xf bank_mask:0xf\n\t"                                         \
         "v_fmac_f32_dpp %[a1], %[r], %[w13] row_ror:13 row_mask:0xf bank_mask:0xf\n\t"                                         \
         "v_fmac_f32_dpp %[a2], %[r], %[w14] row_ror:14 row_mask:0xf bank_mask:0xf\n\t"                                         \
-        "v_fmac_f32_dpp %[a3], %[r], %[w15] row_ror:15 row_mask:0xf bank_mask:0xf"                                             \
-        : [a0] "+v"(acc[0]), [a1] "+v"(acc[1]), [a2] "+v"(acc[2]), [a3] "+v"(acc[3])                                           \
-        : [r] "v"(Rd[G]), [w0] "v"(w[0].v[0]), [w1] "v"(w[0].v[1]), [w2] "v"(w[0].v[2]), [w3] "v"(w[0].v[3]), [w4] "v"(w[1].v[0]), \
+        "v_fmac_f32_dpp %[a3], %[r], %[w15] row_ror:15 row_mask:0xf bank_mask:0xf"
+#define HODE_WS_INS                                                                                                             \
+        [r] "v"(Rd[G]), [w0] "v"(w[0].v[0]), [w1] "v"(w[0].v[1]), [w2] "v"(w[0].v[2]), [w3] "v"(w[0].v[3]), [w4] "v"(w[1].v[0]), \
           [w5] "v"(w[1].v[1]), [w6] "v"(w[1].v[2]), [w7] "v"(w[1].v[3]), [w8] "v"(w[2].v[0]), [w9] "v"(w[2].v[1]),              \
           [w10] "v"(w[2].v[2]), [w11] "v"(w[2].v[3]), [w12] "v"(w[3].v[0]), [w13] "v"(w[3].v[1]), [w14] "v"(w[3].v[2]),         \
-          [w15] "v"(w[3].v[3]))
-    HODE_WS_FM("v_fmac_f32", "");
-#undef HODE_WS_FM
+          [w15] "v"(w[3].v[3])
+    if constexpr (G == 0) {
+        // the first group starts the four sums with products: no zeroed accumulators
+        asm("v_mul_f32 %[a0], %[r], %[w0]\n\t"
+            "v_mul_f32_dpp %[a1], %[r], %[w1] row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+            "v_mul_f32_dpp %[a2], %[r], %[w2] row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+            "v_mul_f32_dpp %[a3], %[r], %[w3] row_ror:3 row_mask:0xf bank_mask:0xf\n\t" HODE_WS_TAIL
+            : [a0] "=&v"(acc[0]), [a1] "=&v"(acc[1]), [a2] "=&v"(acc[2]), [a3] "=&v"(acc[3])
+            : HODE_WS_INS);
+    } else {
+        asm("v_fmac_f32 %[a0], %[r], %[w0]\n\t"
+            "v_fmac_f32_dpp %[a1], %[r], %[w1] row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %[a2], %[r], %[w2] row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %[a3], %[r], %[w3] row_ror:3 row_mask:0xf bank_mask:0xf\n\t" HODE_WS_TAIL
+            : [a0] "+v"(acc[0]), [a1] "+v"(acc[1]), [a2] "+v"(acc[2]), [a3] "+v"(acc[3])
+            : HODE_WS_INS);
+    }
+#undef HODE_WS_TAIL
+#undef HODE_WS_INS
 }
 // U = 1
 __device__ __forceinline__ void ws_wt_mul(const float *__restrict__ wt, int lane, const float (&d)[1], float (&out)[1])
@@ -122,7 +134,7 @@ __device__ __forceinline__ void ws_wt_mul(const float *__restrict__ wt, int lane
     for (int i = 0; i < 4; ++i) w0[i] = wt4[(0 + i) * kMaxH + lane];
 #pragma unroll
     for (int i = 0; i < 4; ++i) w1[i] = wt4[(4 + i) * kMaxH + lane];
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    float acc[4];                                   // started by group 0
     __builtin_amdgcn_sched_barrier(0);
     ws_wt_group<0>(w0, Rd, acc);
     __builtin_amdgcn_sched_barrier(0);
@@ -152,7 +164,7 @@ __device__ __forceinline__ void ws_wt_mul(const float *__restrict__ wt, int lane
     for (int i = 0; i < 4; ++i) w0[i] = wt4[(0 + i) * kMaxH + lane];
 #pragma unroll
     for (int i = 0; i < 4; ++i) w1[i] = wt4[(4 + i) * kMaxH + lane];
-    float aa[4] = {0.f, 0.f, 0.f, 0.f}, ab[4] = {0.f, 0.f, 0.f, 0.f};
+    float aa[4], ab[4];                             // started by group 0
     __builtin_amdgcn_sched_barrier(0);
     ws_wt_group<0>(w0, Ra, aa);
     ws_wt_group<0>(w0, Rb, ab);
@@ -320,6 +332,8 @@ __global__ __launch_bounds__(64 * kWsWaves) void solve_bwd_ws_kernel(const AdjAr
     const int aj = wave - kWsP;                           // accumulation wave index
     const int am = aj % NM, ar = aj / NM;                 // its matrix and its rank among that matrix's waves
     if (isP) {
+        // the propagation waves are the critical path of every iteration: they issue first, the accumulation waves fill the gaps
+        if (!(dbg & 16)) __builtin_amdgcn_s_setprio(2);
         // edge weights in registers (no accumulators here: there is room); per trajectory: step / stage cursors
         R w1[9], w5[6];
         OdeP<R> o;
