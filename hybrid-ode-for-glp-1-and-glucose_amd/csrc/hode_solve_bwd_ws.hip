@@ -122,18 +122,26 @@ template <int G> __device__ __forceinline__ void ws_wt_group(const Vec4<float> (
 #undef HODE_WS_TAIL
 #undef HODE_WS_INS
 }
-// U = 1
-__device__ __forceinline__ void ws_wt_mul(const float *__restrict__ wt, int lane, const float (&d)[1], float (&out)[1])
+// The sixteen 16-byte reads of a matrix are issued ahead of their use: on entry w0 / w1 hold the rows of groups 0 and 1 (loaded
+// while the PREVIOUS matrix -- or, for the first matrix of a stage, the previous iteration's tail -- was being worked on), groups
+// 2 and 3 follow into the buffer the group before them has freed, and on exit w0 / w1 hold groups 0 and 1 of `wt_next`: the
+// propagation wave is one long dependent chain, an LDS round trip per matrix is 3 x ~150 cycles of it.
+__device__ __forceinline__ void ws_wt_preload(const float *__restrict__ wt, int lane, Vec4<float> (&w0)[4], Vec4<float> (&w1)[4])
 {
     const Vec4<float> *wt4 = reinterpret_cast<const Vec4<float> *>(wt);
-    float Rd[4];
-    rows_replicate(d[0], Rd);
-    // rows 4 G .. 4 G + 3 of the image feed group G (r = 16 G + 4 i + c  ->  q = G, n = 4 i + c)
-    Vec4<float> w0[4], w1[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) w0[i] = wt4[(0 + i) * kMaxH + lane];
 #pragma unroll
     for (int i = 0; i < 4; ++i) w1[i] = wt4[(4 + i) * kMaxH + lane];
+}
+// U = 1
+__device__ __forceinline__ void ws_wt_mul(const float *__restrict__ wt, const float *__restrict__ wt_next, int lane, const float (&d)[1],
+                                          float (&out)[1], Vec4<float> (&w0)[4], Vec4<float> (&w1)[4])
+{
+    const Vec4<float> *wt4 = reinterpret_cast<const Vec4<float> *>(wt), *nx4 = reinterpret_cast<const Vec4<float> *>(wt_next);
+    float Rd[4];
+    rows_replicate(d[0], Rd);
+    // rows 4 G .. 4 G + 3 of the image feed group G (r = 16 G + 4 i + c  ->  q = G, n = 4 i + c)
     float acc[4];                                   // started by group 0
     __builtin_amdgcn_sched_barrier(0);
     ws_wt_group<0>(w0, Rd, acc);
@@ -148,22 +156,24 @@ __device__ __forceinline__ void ws_wt_mul(const float *__restrict__ wt, int lane
     __builtin_amdgcn_sched_barrier(0);
     ws_wt_group<2>(w0, Rd, acc);
     __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w0[i] = nx4[(0 + i) * kMaxH + lane];
+    __builtin_amdgcn_sched_barrier(0);
     ws_wt_group<3>(w1, Rd, acc);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w1[i] = nx4[(4 + i) * kMaxH + lane];
     out[0] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
 }
 // U = 2: the same sixteen 16-byte reads feed both trajectories' products (half the LDS traffic per trajectory), and the two
 // accumulator sets are independent instruction chains
-__device__ __forceinline__ void ws_wt_mul(const float *__restrict__ wt, int lane, const float (&d)[2], float (&out)[2])
+__device__ __forceinline__ void ws_wt_mul(const float *__restrict__ wt, const float *__restrict__ wt_next, int lane, const float (&d)[2],
+                                          float (&out)[2], Vec4<float> (&w0)[4], Vec4<float> (&w1)[4])
 {
-    const Vec4<float> *wt4 = reinterpret_cast<const Vec4<float> *>(wt);
+    const Vec4<float> *wt4 = reinterpret_cast<const Vec4<float> *>(wt), *nx4 = reinterpret_cast<const Vec4<float> *>(wt_next);
     float Ra[4], Rb[4];
     rows_replicate(d[0], Ra);
     rows_replicate(d[1], Rb);
-    Vec4<float> w0[4], w1[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) w0[i] = wt4[(0 + i) * kMaxH + lane];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) w1[i] = wt4[(4 + i) * kMaxH + lane];
     float aa[4], ab[4];                             // started by group 0
     __builtin_amdgcn_sched_barrier(0);
     ws_wt_group<0>(w0, Ra, aa);
@@ -181,8 +191,14 @@ __device__ __forceinline__ void ws_wt_mul(const float *__restrict__ wt, int lane
     ws_wt_group<2>(w0, Ra, aa);
     ws_wt_group<2>(w0, Rb, ab);
     __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w0[i] = nx4[(0 + i) * kMaxH + lane];
+    __builtin_amdgcn_sched_barrier(0);
     ws_wt_group<3>(w1, Ra, aa);
     ws_wt_group<3>(w1, Rb, ab);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w1[i] = nx4[(4 + i) * kMaxH + lane];
     out[0] = (aa[0] + aa[1]) + (aa[2] + aa[3]);
     out[1] = (ab[0] + ab[1]) + (ab[2] + ab[3]);
 }
@@ -404,6 +420,8 @@ __global__ __launch_bounds__(64 * kWsWaves) void solve_bwd_ws_kernel(const AdjAr
                 finish_traj(u);
             }
         };
+        Vec4<float> wq0[4], wq1[4];                        // the two row groups of the transposed matrices that are read ahead
+        ws_wt_preload(wt + (size_t)(NM - 1) * kMaxH * kMaxH, lane, wq0, wq1);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             bi_next[u] = (wave * U + u) * gridDim.x + blockIdx.x;
@@ -508,7 +526,8 @@ __global__ __launch_bounds__(64 * kWsWaves) void solve_bwd_ws_kernel(const AdjAr
 #pragma unroll
                     for (int u = 0; u < U; ++u) dp[u] = d[u] * 0.5f;
                 } else {
-                    ws_wt_mul(wt + (size_t)(l - 1) * kMaxH * kMaxH, lane, d, dp);
+                    // (the matrix after this one: l - 2, or -- behind the last -- the first matrix of the next stage)
+                    ws_wt_mul(wt + (size_t)(l - 1) * kMaxH * kMaxH, wt + (size_t)(l >= 2 ? l - 2 : NM - 1) * kMaxH * kMaxH, lane, d, dp, wq0, wq1);
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
@@ -651,7 +670,7 @@ template <int NL, bool GODE, bool GD> static int launch_ws_g(hipStream_t s, cons
     if (blocks < 1) blocks = 1;
     if (a.partials == nullptr || blocks * a.n_sets > a.partial_rows) return HODE_EUNSUPPORTED;     // caller falls back
     // two trajectories per propagation wave as soon as a workgroup has more than eight to process
-    int two = per_set > blocks * kWsP;
+    int two = per_set > blocks * kWsP && !GODE;          // (with the 17 ODE-constant partials the two-trajectory instantiation spills)
 #ifdef HODE_LAB
     static const int dbg = [] { const char *e = getenv("HODE_WS_DBG"); return e ? atoi(e) : 0; }();
     method |= (dbg & 0xff) << 8;
