@@ -491,7 +491,7 @@ def main():
         fwt_bytes = st_steps * (6 * STAGE_REC_BYTES + 36) + B * BYTES_FWD_PER_TRAJ
         tr_adj, src_adj = measured_traffic("solve_bwd_hbm_bytes_per_launch")
         tr_fwt, _ = measured_traffic("solve_fwd_tape_hbm_bytes_per_launch")
-        roof = {"adjoint": {"kernel": "solve_bwd_kernel<float,4>", "kernel_ms": ms_adj, "bound": "valu_fp32",
+        roof = {"adjoint": {"kernel": "solve_bwd_ws_kernel<4,2> (wave-specialised: 8 propagation + 8 accumulation waves per CU) + adj_reduce_kernel", "kernel_ms": ms_adj, "bound": "valu_fp32",
                             "achieved": adj_flops / (ms_adj * 1e-3) / 1e12, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                             "frac": adj_flops / (ms_adj * 1e-3) / 1e12 / PEAK_FP32_TFLOPS, "algorithmic_flops_per_launch": adj_flops,
                             "flops_model": "2 x forward RHS flops per stage (dW outer products + W^T delta products; no recompute)",

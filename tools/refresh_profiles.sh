@@ -3,7 +3,7 @@
 # (the PMC stamp must be written BEFORE bench.py runs, and stale files under gpurun_out/ must not be averaged in).
 #   tools/refresh_profiles.sh [tag]        e.g.  tools/refresh_profiles.sh r03
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 cd "$(dirname "$0")/.."
 GPURUN=/usr/local/graft/bin/gpurun
 rm -rf gpurun_out/prof_$TAG
