@@ -336,24 +336,40 @@ __global__ __launch_bounds__(WTREG ? 256 : 64 * kBwdWaves, (sizeof(R) == 4 && !W
     }
 }
 
-// second pass of the adjoint's gradient reduction: row sums in workgroup order (fixed), added to gnn / gode
+// second pass of the adjoint's gradient reduction: row sums in a FIXED order, added to gnn / gode.  A workgroup takes 32
+// columns; its eight row groups add the rows w = r, r + 8, ... (four loads in flight each) and are then combined in group order --
+// the same order for the same launch geometry, so the result is reproducible bit for bit.  (One thread per column walking all
+// rows took 95 us for 256 rows of 54 KB: a chain of 256 dependent-issue loads; this form is bandwidth-bound, ~10 us.)
 template <typename R>
 __global__ __launch_bounds__(256) void adj_reduce_kernel(const R *__restrict__ partials, const int rowlen, const int blocks_per_set, const int P,
                                                          R *__restrict__ gnn, R *__restrict__ gode)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x, set = blockIdx.y;
-    if (i >= P + 17) return;
-    if (i < P ? gnn == nullptr : gode == nullptr) return;
-    const R *__restrict__ p = partials + (size_t)set * blocks_per_set * rowlen + i;
+    __shared__ R part[8][32];
+    const int c = threadIdx.x & 31, r = threadIdx.x >> 5, i = blockIdx.x * 32 + c, set = blockIdx.y;
     R v = R(0);
-    for (int w = 0; w < blocks_per_set; ++w) v += p[(size_t)w * rowlen];
-    if (i < P) gnn[(size_t)set * P + i] += v;
-    else gode[(size_t)set * 17 + (i - P)] += v;
+    if (i < P + 17) {
+        const R *__restrict__ p = partials + (size_t)set * blocks_per_set * rowlen + i;
+        int w = r;
+        for (; w + 24 < blocks_per_set; w += 32) {
+            const R a0 = p[(size_t)w * rowlen], a1 = p[(size_t)(w + 8) * rowlen], a2 = p[(size_t)(w + 16) * rowlen], a3 = p[(size_t)(w + 24) * rowlen];
+            v += a0; v += a1; v += a2; v += a3;
+        }
+        for (; w < blocks_per_set; w += 8) v += p[(size_t)w * rowlen];
+    }
+    part[r][c] = v;
+    __syncthreads();
+    if (r == 0 && i < P + 17 && !(i < P ? gnn == nullptr : gode == nullptr)) {
+        R t = part[0][c];
+#pragma unroll
+        for (int q = 1; q < 8; ++q) t += part[q][c];
+        if (i < P) gnn[(size_t)set * P + i] += t;
+        else gode[(size_t)set * 17 + (i - P)] += t;
+    }
 }
 
 void launch_adj_reduce(hipStream_t s, const float *partials, int rowlen, int blocks_per_set, int n_sets, int P, float *gnn, float *gode)
 {
-    hipLaunchKernelGGL(adj_reduce_kernel<float>, dim3((P + 17 + 255) / 256, n_sets), dim3(256), 0, s, partials, rowlen, blocks_per_set, P, gnn, gode);
+    hipLaunchKernelGGL(adj_reduce_kernel<float>, dim3((P + 17 + 31) / 32, n_sets), dim3(256), 0, s, partials, rowlen, blocks_per_set, P, gnn, gode);
 }
 
 // compute units of the current device (one adjoint workgroup per CU); queried once per device, never assumed
@@ -390,7 +406,7 @@ template <typename R, int NL, bool GODE, bool WTREG, bool GD> static int launch_
     hipLaunchKernelGGL(kern, grid, block, lds, s, a2, method);
     if (a2.partials && (a.gnn || (GODE && a.gode))) {
         const int rowlen = (int)adj_partial_rowlen(a.P);
-        hipLaunchKernelGGL(adj_reduce_kernel<R>, dim3((a.P + 17 + 255) / 256, a.n_sets), dim3(256), 0, s, a2.partials, rowlen, blocks, a.P,
+        hipLaunchKernelGGL(adj_reduce_kernel<R>, dim3((a.P + 17 + 31) / 32, a.n_sets), dim3(256), 0, s, a2.partials, rowlen, blocks, a.P,
                            a.gnn, GODE ? a.gode : (R *)nullptr);
     }
     return hipGetLastError() == hipSuccess ? HODE_OK : HODE_ELAUNCH;
