@@ -108,9 +108,15 @@ template <typename R> struct RhsStream {
 };
 
 // J^T kb for an arbitrary network from a stage record.  g: gradient vector of this parameter set (or nullptr).
-template <typename R, bool GODE, bool GT>
+// NW > 1: a TEAM of NW waves works on the same stage of the same trajectory (solve_bwd_generic_kernel).  Every wave runs the whole
+// function on identical data -- identical results, identical control flow -- except for the two loops over the rows of a hidden
+// matrix, which are split: wave `part` takes rows [j0, j1) of W^T delta (partial sums exchanged through xch[NW][2][64] in LDS and
+// added in wave order) and of the atomics dW += delta (x) h_in.  A trajectory of such a network is one long chain of L2 round
+// trips; with the batches these shapes are trained on (32 trajectories) one wave per trajectory left 97 % of the chip idle.
+template <typename R, bool GODE, bool GT, int NW = 1>
 __device__ __forceinline__ R rhs_vjp_stream(const StreamNet<R> &n, R *__restrict__ g, const OdeP<R> &o, R t, R tvns, R gde, R gd_in,
-                                            bool use_gd, int lane, const R *__restrict__ rec, R kb, R &go, R *gt_out)
+                                            bool use_gd, int lane, const R *__restrict__ rec, R kb, R &go, R *gt_out, int part = 0,
+                                            R *__restrict__ xch = nullptr)
 {
     const int H = n.H, L = n.L;
     const R *__restrict__ sx = rec + 2 * L * kWave;            // the stage state: wave-uniform loads
@@ -120,6 +126,10 @@ __device__ __forceinline__ R rhs_vjp_stream(const StreamNet<R> &n, R *__restrict
     const R mech = mech_vjp<R, GODE>(o, G, I, Glu, GLP1, FFA, lq[0], lq[1], lq[2], lq[3], lq[5], gde, gd_in, use_gd, lane, go);
     const bool vA = lane < H, vB = lane + 64 < H;
     const int jA = vA ? lane : 0, jB = vB ? lane + 64 : 0;
+    // this wave's rows of every hidden matrix (multiples of 8: the chunked loads below), and who adds the non-matrix gradients
+    const int rows_per = (((H + NW - 1) / NW) + 7) & ~7;
+    const int j0 = (part * rows_per < H) ? part * rows_per : H, j1 = (j0 + rows_per < H) ? j0 + rows_per : H;
+    R *__restrict__ gedge = (part == 0) ? g : nullptr;                   // biases, first and last layer: the team's first wave
     // output layer
     R hA = rec[(2 * (L - 1)) * kWave + lane], hB = rec[(2 * (L - 1) + 1) * kWave + lane];
     R dA = R(0), dB = R(0);
@@ -127,12 +137,12 @@ __device__ __forceinline__ R rhs_vjp_stream(const StreamNet<R> &n, R *__restrict
     for (int q = 0; q < 6; ++q) {
         dA = rfma(n.Wo()[q * H + jA], lq[q], dA);
         dB = rfma(n.Wo()[q * H + jB], lq[q], dB);
-        if (g) {
-            if (vA) atomic_add(g + n.out_off() + q * H + jA, lq[q] * hA);
-            if (vB) atomic_add(g + n.out_off() + q * H + jB, lq[q] * hB);
+        if (gedge) {
+            if (vA) atomic_add(gedge + n.out_off() + q * H + jA, lq[q] * hA);
+            if (vB) atomic_add(gedge + n.out_off() + q * H + jB, lq[q] * hB);
         }
     }
-    if (g && lane < 6) atomic_add(g + n.out_off() + 6 * H + lane, kb);
+    if (gedge && lane < 6) atomic_add(gedge + n.out_off() + 6 * H + lane, kb);
     dA = (vA && hA > R(0)) ? dA : R(0);
     dB = (vB && hB > R(0)) ? dB : R(0);
     // hidden matrices, last to first: matrix l maps h_l (rows 2l, 2l+1 of the record) to h_{l+1}
@@ -140,7 +150,7 @@ __device__ __forceinline__ R rhs_vjp_stream(const StreamNet<R> &n, R *__restrict
         const R inA = rec[(2 * l) * kWave + lane], inB = rec[(2 * l + 1) * kWave + lane];
         const R *__restrict__ W = n.Wh(l);
         R *__restrict__ gW = g ? g + n.hid_off(l) : nullptr;
-        if (g) {
+        if (gedge) {
             if (vA) atomic_add(gW + (size_t)H * H + jA, dA);
             if (vB) atomic_add(gW + (size_t)H * H + jB, dB);
         }
@@ -149,8 +159,8 @@ __device__ __forceinline__ R rhs_vjp_stream(const StreamNet<R> &n, R *__restrict
         // the previous chunk's atomics (29 ms per 32 x 61 adjoint of the 5 x 128 network).  Pass 1 only loads (W^T delta),
         // pass 2 only adds (dW += delta (x) h_in).
         R pA = R(0), pB = R(0);
-        int j = 0;
-        for (; j + 8 <= H; j += 8) {                           // eight rows at a time: 16 independent loads in flight
+        int j = j0;
+        for (; j + 8 <= j1; j += 8) {                          // eight rows at a time: 16 independent loads in flight
             R wA[8], wB[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -165,14 +175,24 @@ __device__ __forceinline__ R rhs_vjp_stream(const StreamNet<R> &n, R *__restrict
                 pB = rfma(wB[u], dj, pB);
             }
         }
-        for (; j < H; ++j) {
+        for (; j < j1; ++j) {
             const R dj = unit_bcast(dA, dB, j);
             const R *__restrict__ row = W + (size_t)j * H;
             pA = rfma(row[jA], dj, pA);
             pB = rfma(row[jB], dj, pB);
         }
+        if constexpr (NW > 1) {
+            // partial sums of the team, added in wave order on every wave (same bits everywhere)
+            xch[(part * 2 + 0) * kWave + lane] = pA;
+            xch[(part * 2 + 1) * kWave + lane] = pB;
+            __syncthreads();
+            pA = R(0); pB = R(0);
+#pragma unroll
+            for (int w = 0; w < NW; ++w) { pA += xch[(w * 2 + 0) * kWave + lane]; pB += xch[(w * 2 + 1) * kWave + lane]; }
+            __syncthreads();
+        }
         if (g) {
-            for (j = 0; j < H; ++j) {
+            for (j = j0; j < j1; ++j) {
                 const R dj = unit_bcast(dA, dB, j);
                 if (dj == R(0)) continue;                      // wave-uniform: no atomics for dead units
                 if (vA) atomic_add(gW + (size_t)j * H + jA, dj * inA);
@@ -184,13 +204,13 @@ __device__ __forceinline__ R rhs_vjp_stream(const StreamNet<R> &n, R *__restrict
     }
     // first layer: input row [t, G, I, Glu, GLP1, GE, FFA, glp1 := GLP1, tvns]
     const R in[9] = {t, G, I, Glu, GLP1, GE, FFA, GLP1, tvns};
-    if (g) {
-        if (vA) atomic_add(g + 9 * H + jA, dA);
-        if (vB) atomic_add(g + 9 * H + jB, dB);
+    if (gedge) {
+        if (vA) atomic_add(gedge + 9 * H + jA, dA);
+        if (vB) atomic_add(gedge + 9 * H + jB, dB);
 #pragma unroll
         for (int i = 0; i < 9; ++i) {
-            if (vA) atomic_add(g + jA * 9 + i, dA * in[i]);
-            if (vB) atomic_add(g + jB * 9 + i, dB * in[i]);
+            if (vA) atomic_add(gedge + jA * 9 + i, dA * in[i]);
+            if (vB) atomic_add(gedge + jB * 9 + i, dB * in[i]);
         }
     }
     R w[9];
@@ -307,17 +327,20 @@ template <typename R> int launch_solve_fwd_generic(hipStream_t s, const SolveArg
 // ------------------------------------------------------------------------------------------ K4
 // Same walk over the tape as solve_bwd_kernel (hode_solve_bwd.hip); records are read from HBM with plain loads (L2 hits:
 // the forward has just written them), gradients leave through atomics inside rhs_vjp_stream.
+constexpr int kGenTeam = 8;           // waves per trajectory in the generic adjoint (rows of a 128 x 128 matrix: 16 each)
 template <typename R, bool GODE, bool GD>
-__global__ __launch_bounds__(64) void solve_bwd_generic_kernel(const AdjArgs<R> a, const int method, const int L)
+__global__ __launch_bounds__(64 * kGenTeam) void solve_bwd_generic_kernel(const AdjArgs<R> a, const int method, const int L)
 {
     __shared__ R rowsT[8 * kWave];
-    const int lane = threadIdx.x;
+    __shared__ R xch[kGenTeam * 2 * kWave];
+    const int lane = threadIdx.x & 63;
+    const int part = first_lane((int)(threadIdx.x >> 6));      // every wave of the team walks the tape; the matrix rows are split
     const int c8 = lane & 7, grp = lane >> 3;
     const int T = a.T;
     const TableauData &tab = kTableau[method];
     const int S = tab.S;
     const int kSlot = 2 * L * kWave + 8;
-    tableau_rowsT_store<R>(rowsT, method, lane, 64);
+    tableau_rowsT_store<R>(rowsT, method, threadIdx.x, 64 * kGenTeam);
     __syncthreads();
     const int per_set = a.B / a.n_sets;
     constexpr bool use_gd = GD;
@@ -368,8 +391,8 @@ __global__ __launch_bounds__(64) void solve_bwd_generic_kernel(const AdjArgs<R> 
                 const R gdv = rfma(al, dd, d0);
                 R gde = R(0);
                 if constexpr (use_gd) gde = gd_effect(o, gdv);
-                const R Z = rhs_vjp_stream<R, GODE, false>(n, g, o, ts, rfma(al, dv, v0), gde, gdv, use_gd, lane,
-                                                           stg + ((size_t)st * 6 + s) * kSlot, kb, go, nullptr);
+                const R Z = rhs_vjp_stream<R, GODE, false, kGenTeam>(n, g, o, ts, rfma(al, dv, v0), gde, gdv, use_gd, lane,
+                                                                     stg + ((size_t)st * 6 + s) * kSlot, kb, go, nullptr, part, xch);
                 ZZ = (grp == s) ? Z : ZZ;
             }
             lam += group_sum8(rowsT[7 * kWave + lane] * ZZ);
@@ -377,16 +400,18 @@ __global__ __launch_bounds__(64) void solve_bwd_generic_kernel(const AdjArgs<R> 
         int kf = 0;                                           // rows 0..kf are (copies of) x0
         while (kf + 1 < T && !(tg[kf + 1] > tg[kf])) ++kf;
         for (int r = 0; r <= kf; ++r) lam += gy_row(r);
-        if (lane < 6) a.gx0[(size_t)b * 6 + lane] = lam;
-        if constexpr (GODE) {
-            if (a.gode && lane < 17) atomic_add(a.gode + 17 * set + lane, go);
+        if (part == 0) {
+            if (lane < 6) a.gx0[(size_t)b * 6 + lane] = lam;
+            if constexpr (GODE) {
+                if (a.gode && lane < 17) atomic_add(a.gode + 17 * set + lane, go);
+            }
         }
     }
 }
 
 template <typename R> int launch_solve_bwd_generic(hipStream_t s, const AdjArgs<R> &a, int L, int method)
 {
-    const dim3 grid(a.B < 4096 ? a.B : 4096), block(64);
+    const dim3 grid(a.B < 4096 ? a.B : 4096), block(64 * kGenTeam);
     const bool gd = a.gd_mode != 0;
     if (a.gode) {
         if (gd) hipLaunchKernelGGL((solve_bwd_generic_kernel<R, true, true>), grid, block, 0, s, a, method, L);
