@@ -327,8 +327,9 @@ template <typename R> int launch_solve_fwd_generic(hipStream_t s, const SolveArg
 // ------------------------------------------------------------------------------------------ K4
 // Same walk over the tape as solve_bwd_kernel (hode_solve_bwd.hip); records are read from HBM with plain loads (L2 hits:
 // the forward has just written them), gradients leave through atomics inside rhs_vjp_stream.
-constexpr int kGenTeam = 8;           // waves per trajectory in the generic adjoint (rows of a 128 x 128 matrix: 16 each)
-template <typename R, bool GODE, bool GD>
+// waves per trajectory in the generic adjoint: 16 for H > 64 (eight rows of a 128 x 128 matrix each = one chunk of loads;
+// 32 x 61 of the 5 x 128 network: 22.4 ms with one wave per trajectory, 10.6 with 8, 9.0 with 16), 8 up to H = 64 (4.4 / 5.8 ms)
+template <typename R, bool GODE, bool GD, int kGenTeam>
 __global__ __launch_bounds__(64 * kGenTeam) void solve_bwd_generic_kernel(const AdjArgs<R> a, const int method, const int L)
 {
     __shared__ R rowsT[8 * kWave];
@@ -409,18 +410,22 @@ __global__ __launch_bounds__(64 * kGenTeam) void solve_bwd_generic_kernel(const 
     }
 }
 
-template <typename R> int launch_solve_bwd_generic(hipStream_t s, const AdjArgs<R> &a, int L, int method)
+template <typename R, int NW> static int launch_bwd_generic_t(hipStream_t s, const AdjArgs<R> &a, int L, int method)
 {
-    const dim3 grid(a.B < 4096 ? a.B : 4096), block(64 * kGenTeam);
+    const dim3 grid(a.B < 4096 ? a.B : 4096), block(64 * NW);
     const bool gd = a.gd_mode != 0;
     if (a.gode) {
-        if (gd) hipLaunchKernelGGL((solve_bwd_generic_kernel<R, true, true>), grid, block, 0, s, a, method, L);
-        else hipLaunchKernelGGL((solve_bwd_generic_kernel<R, true, false>), grid, block, 0, s, a, method, L);
+        if (gd) hipLaunchKernelGGL((solve_bwd_generic_kernel<R, true, true, NW>), grid, block, 0, s, a, method, L);
+        else hipLaunchKernelGGL((solve_bwd_generic_kernel<R, true, false, NW>), grid, block, 0, s, a, method, L);
     } else {
-        if (gd) hipLaunchKernelGGL((solve_bwd_generic_kernel<R, false, true>), grid, block, 0, s, a, method, L);
-        else hipLaunchKernelGGL((solve_bwd_generic_kernel<R, false, false>), grid, block, 0, s, a, method, L);
+        if (gd) hipLaunchKernelGGL((solve_bwd_generic_kernel<R, false, true, NW>), grid, block, 0, s, a, method, L);
+        else hipLaunchKernelGGL((solve_bwd_generic_kernel<R, false, false, NW>), grid, block, 0, s, a, method, L);
     }
     return hipGetLastError() == hipSuccess ? HODE_OK : HODE_ELAUNCH;
+}
+template <typename R> int launch_solve_bwd_generic(hipStream_t s, const AdjArgs<R> &a, int L, int method)
+{
+    return a.H > 64 ? launch_bwd_generic_t<R, 16>(s, a, L, method) : launch_bwd_generic_t<R, 8>(s, a, L, method);
 }
 
 template int launch_rhs_fwd_generic<float>(hipStream_t, const RhsArgs<float> &, int);
