@@ -40,9 +40,11 @@ __device__ __forceinline__ double bcast_dyn(double v, int k) { return lane_bcast
 template <typename R> __device__ __forceinline__ R unit_bcast(R a, R b, int k) { return k < 64 ? bcast_dyn(a, k) : bcast_dyn(b, k - 64); }
 
 // f(t, x, u) for an arbitrary network.  rec != nullptr: record h_1..h_L (two rows of 64 each) and the stage state (8 reals).
-template <typename R>
+// NW > 1: a team of NW waves evaluates the same f on identical data (see rhs_vjp_stream); the columns k of every hidden matrix
+// are split over the waves, partial sums exchanged through xch[NW][2][64] and added in wave order on every wave.
+template <typename R, int NW = 1>
 __device__ __forceinline__ R rhs_stream(const StreamNet<R> &n, const OdeP<R> &o, R t, R Y, R meal, R tvns, R gde, int lane,
-                                        R *__restrict__ rec)
+                                        R *__restrict__ rec, int part = 0, R *__restrict__ xch = nullptr)
 {
     const int H = n.H, L = n.L;
     const R G = lane_bcast(Y, 0), I = lane_bcast(Y, 1), Glu = lane_bcast(Y, 2), GLP1 = lane_bcast(Y, 3),
@@ -61,13 +63,15 @@ __device__ __forceinline__ R rhs_stream(const StreamNet<R> &n, const OdeP<R> &o,
     hA = vA ? rmax0(hA) : R(0);
     hB = vB ? rmax0(hB) : R(0);
     if (rec) { rec[lane] = hA; rec[kWave + lane] = hB; }
+    const int cols_per = (((H + NW - 1) / NW) + 7) & ~7;             // this wave's columns: a multiple of 8 (the chunked loads)
+    const int k0 = (part * cols_per < H) ? part * cols_per : H, k1 = (k0 + cols_per < H) ? k0 + cols_per : H;
     for (int l = 0; l + 1 < L; ++l) {
         const R *__restrict__ rowA = n.Wh(l) + (size_t)jA * H, *__restrict__ rowB = n.Wh(l) + (size_t)jB * H;
-        R aA = n.bh(l)[jA], aB = n.bh(l)[jB];
+        R aA = (NW == 1) ? n.bh(l)[jA] : R(0), aB = (NW == 1) ? n.bh(l)[jB] : R(0);
         // chunks of 8 columns: 16 independent loads in flight, then the 16 FMAs (one load, one dependent FMA at a time left
         // a lone wave waiting out an L2 round trip per column: 21.9 ms per 32 x 61 forward of the 5 x 128 network, 7.7 ms now)
-        int k = 0;
-        for (; k + 8 <= H; k += 8) {
+        int k = k0;
+        for (; k + 8 <= k1; k += 8) {
             R wA[8], wB[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) { wA[u] = rowA[k + u]; wB[u] = rowB[k + u]; }
@@ -78,10 +82,19 @@ __device__ __forceinline__ R rhs_stream(const StreamNet<R> &n, const OdeP<R> &o,
                 aB = rfma(wB[u], hk, aB);
             }
         }
-        for (; k < H; ++k) {
+        for (; k < k1; ++k) {
             const R hk = unit_bcast(hA, hB, k);
             aA = rfma(rowA[k], hk, aA);
             aB = rfma(rowB[k], hk, aB);
+        }
+        if constexpr (NW > 1) {
+            xch[(part * 2 + 0) * kWave + lane] = aA;
+            xch[(part * 2 + 1) * kWave + lane] = aB;
+            __syncthreads();
+            aA = n.bh(l)[jA]; aB = n.bh(l)[jB];
+#pragma unroll
+            for (int w = 0; w < NW; ++w) { aA += xch[(w * 2 + 0) * kWave + lane]; aB += xch[(w * 2 + 1) * kWave + lane]; }
+            __syncthreads();
         }
         hA = vA ? rmax0(aA) : R(0);
         hB = vB ? rmax0(aB) : R(0);
@@ -96,14 +109,17 @@ __device__ __forceinline__ R rhs_stream(const StreamNet<R> &n, const OdeP<R> &o,
     return (c8 < 6) ? (mech + nn + bout) : R(0);
 }
 
-template <typename R> struct RhsStream {
+template <typename R, int NW = 1> struct RhsStream {
     StreamNet<R> n;
     const OdeP<R> &o;
     int lane;
+    int part;               // this wave's index in its team (NW > 1: hode_generic.hip solve_fwd_generic_kernel)
+    R *xch;                 // the team's exchange area
     __device__ __forceinline__ int slot_elems() const { return 2 * n.L * kWave + 8; }
     __device__ __forceinline__ R operator()(R ts, R Ys, R meal, R tvns, R gde, R *__restrict__ rec) const
     {
-        return rhs_stream<R>(n, o, ts, Ys, meal, tvns, gde, lane, rec);
+        // every wave of a team computes the same f; only the first one writes the stage record
+        return rhs_stream<R, NW>(n, o, ts, Ys, meal, tvns, gde, lane, part == 0 ? rec : nullptr, part, xch);
     }
 };
 
@@ -288,36 +304,50 @@ template <typename R> int launch_rhs_bwd_generic(hipStream_t s, const RhsArgs<R>
 }
 
 // ------------------------------------------------------------------------------------------ K2 + K3
-template <typename R, int METHOD, bool TAPE, bool GD>
-__global__ __launch_bounds__(64) void solve_fwd_generic_kernel(const SolveArgs<R> a)
+// A team of NW waves per trajectory.  Every wave runs the integration (solve_one) on identical data -- identical step-size
+// decisions, identical control flow -- and the team splits the columns of the hidden matrices inside the right-hand side.
+// NW = 1 for batches that fill the chip with one wave per trajectory; the reference trains these shapes on 32 trajectories
+// (forward 7.6 ms for 32 x 61 of the 5 x 128 network with one wave each: 97 % of the chip idle).  The waves of a team write the
+// same y / tape values to the same addresses (benign: identical bits); the stage records are written by the first wave only.
+template <typename R, int METHOD, bool TAPE, bool GD, int NW>
+__global__ __launch_bounds__(64 * NW) void solve_fwd_generic_kernel(const SolveArgs<R> a)
 {
     __shared__ R rows[8 * kWave];
     __shared__ R cvec[8];
-    __shared__ R ybuf[kWave + 8];
-    const int lane = threadIdx.x;
+    __shared__ R ybuf[NW * (kWave + 8)];
+    __shared__ R xch[NW * 2 * kWave];
+    const int lane = threadIdx.x & 63;
+    const int part = first_lane((int)(threadIdx.x >> 6));
     const int b = blockIdx.x;
     const int set = b / (a.B / a.n_sets);
-    tableau_rows_store<R>(rows, METHOD, lane, 64);
-    if (lane < 8) cvec[lane] = (R)kTableau[METHOD].c[lane];
+    tableau_rows_store<R>(rows, METHOD, threadIdx.x, 64 * NW);
+    if (threadIdx.x < 8) cvec[threadIdx.x] = (R)kTableau[METHOD].c[threadIdx.x];
     OdeP<R> o;
     ode_load(o, a.ode_p + 17 * set);
     __syncthreads();
-    const RhsStream<R> rhs{StreamNet<R>{a.nn_p + (size_t)set * a.P, a.H, a.L}, o, lane};
-    solve_one<R, METHOD, TAPE, GD>(a, b, rhs, o, rows, cvec, ybuf, lane);
+    const RhsStream<R, NW> rhs{StreamNet<R>{a.nn_p + (size_t)set * a.P, a.H, a.L}, o, lane, part, xch};
+    solve_one<R, METHOD, TAPE, GD>(a, b, rhs, o, rows, cvec, ybuf + part * (kWave + 8), lane);
 }
 
-template <typename R, int METHOD> static int launch_fwd_generic_m(hipStream_t s, const SolveArgs<R> &a)
+template <typename R, int METHOD, int NW> static int launch_fwd_generic_t(hipStream_t s, const SolveArgs<R> &a)
 {
     const bool tape = a.tape != nullptr, gd = a.gd_mode != 0;
-    const dim3 grid(a.B), block(64);
+    const dim3 grid(a.B), block(64 * NW);
     if (tape) {
-        if (gd) hipLaunchKernelGGL((solve_fwd_generic_kernel<R, METHOD, true, true>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((solve_fwd_generic_kernel<R, METHOD, true, false>), grid, block, 0, s, a);
+        if (gd) hipLaunchKernelGGL((solve_fwd_generic_kernel<R, METHOD, true, true, NW>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((solve_fwd_generic_kernel<R, METHOD, true, false, NW>), grid, block, 0, s, a);
     } else {
-        if (gd) hipLaunchKernelGGL((solve_fwd_generic_kernel<R, METHOD, false, true>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((solve_fwd_generic_kernel<R, METHOD, false, false>), grid, block, 0, s, a);
+        if (gd) hipLaunchKernelGGL((solve_fwd_generic_kernel<R, METHOD, false, true, NW>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((solve_fwd_generic_kernel<R, METHOD, false, false, NW>), grid, block, 0, s, a);
     }
     return hipGetLastError() == hipSuccess ? HODE_OK : HODE_ELAUNCH;
+}
+template <typename R, int METHOD> static int launch_fwd_generic_m(hipStream_t s, const SolveArgs<R> &a)
+{
+    // teams while one wave per trajectory would leave most SIMDs empty (1 024 of them): 8 columns of a 128-wide matrix per wave
+    if (a.B <= 128) return a.H > 64 ? launch_fwd_generic_t<R, METHOD, 16>(s, a) : launch_fwd_generic_t<R, METHOD, 8>(s, a);
+    if (a.B <= 512) return launch_fwd_generic_t<R, METHOD, 4>(s, a);
+    return launch_fwd_generic_t<R, METHOD, 1>(s, a);
 }
 template <typename R> int launch_solve_fwd_generic(hipStream_t s, const SolveArgs<R> &a, int method)
 {

@@ -87,8 +87,9 @@ def train_step(state: TrainState, compute: Callable[[torch.Tensor], Tuple[torch.
     collective through host memory (gloo rehearsal of the multi-rank path on a single GPU)."""
     P = state.p.numel()
     loss_sum, gnn, gode, n_local = compute(state.p)
-    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
-        # one rank: nothing to exchange, no message to build
+    if not (dist.is_available() and dist.is_initialized()):
+        # no process group (a plain single-GPU run): nothing to exchange, no message to build.  (With a group -- also one of
+        # size 1 -- the step goes through the message and the collective: that is how the RCCL path is exercised on one GPU)
         state.step += 1
         if optimizer is not None:
             optimizer(state, gnn.float())

@@ -90,3 +90,53 @@ def test_bench_two_ranks_uneven_shards_is_the_single_process_step_on_the_whole_c
         tot += float(ls)
     first = out["train_step"]["loss_first_last"][0]
     assert abs(first - tot / (N * 241 * 6)) < 1e-6 * first
+
+
+def test_rccl_backend_one_rank_runs_the_data_parallel_step_and_the_sharded_elbo(tmp_path):
+    """The RCCL path itself ("nccl" backend: device-tensor all_reduce of the fp64 message, `elbo(group=...)`'s gradient
+    collective) on the one GPU a test box has: a process group of ONE rank.  It cannot show scaling, but it executes
+    `dist.init_process_group("nccl", device_id=...)`, the collectives on device buffers and the code around them exactly as an
+    8-rank job does (that path had never run).  Results must be the bits of the same step without a group."""
+    code = f"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, {ROOT!r}); sys.path.insert(0, {os.path.join(ROOT, "hybrid-ode-for-glp-1-and-glucose_amd")!r})
+import bench, hode, models
+dev = torch.device("cuda", 0); torch.cuda.set_device(dev)
+x0, t, meal, tv = (v.to(dev) for v in bench.synth_cohort(64, 3))
+nn_t, ode = bench.synth_weights(0).to(dev), bench.ODE_DEFAULT.to(dev)
+obs, student = bench.train_problem(dev, x0, t, meal, tv, ode, nn_t, 0)
+def run(n_steps):
+    state = hode.train.TrainState(student.clone())
+    def compute(p):
+        ls, gnn, gode, _ = hode.train.hip_loss_and_grads(p, ode, x0, t, meal, tv, obs, 64, 4, obs.numel(), state=state)
+        return ls, gnn, gode, obs.numel()
+    losses = [float(hode.train.train_step(state, compute)) for _ in range(n_steps)]
+    return state.p.clone(), losses
+p_plain, l_plain = run(2)
+def vi():
+    torch.manual_seed(0)
+    m = models.HybridODENN(nn_hidden=16, nn_layers=2, use_variational=True, device=dev)
+    with torch.no_grad():
+        for n_, p_ in m.variational_params.means.items():
+            if n_.startswith("ode_"): p_.copy_(getattr(m.ode_core, n_[4:]))
+        for p_ in m.variational_params.log_stds.values(): p_.fill_(-6.0)
+    return m
+batch = {{"initial_state": x0[:8], "observations": obs[:8, :31].contiguous(), "time_points": t[:31].contiguous(),
+         "external_inputs": {{"meal": meal[:8, :31].contiguous(), "tVNS": tv[:8, :31].contiguous()}}}}
+m = vi(); torch.manual_seed(1); e0 = m.elbo(batch, n_samples=3, noise_sigma=1.0); e0.backward()
+g0 = torch.cat([p_.grad.reshape(-1) for p_ in m.variational_params.means.values()]).clone()
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT={str(_free_port())!r}, RANK="0", WORLD_SIZE="1")
+dist.init_process_group("nccl", device_id=dev)            # "nccl" IS RCCL on ROCm
+assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
+p_grp, l_grp = run(2)
+m = vi(); torch.manual_seed(1); e1 = m.elbo(batch, n_samples=3, noise_sigma=1.0, group=True); e1.backward()
+g1 = torch.cat([p_.grad.reshape(-1) for p_ in m.variational_params.means.values()]).clone()
+dist.barrier(); torch.cuda.synchronize(); dist.destroy_process_group()
+assert torch.equal(p_plain, p_grp), float((p_plain - p_grp).abs().max())
+assert max(abs(a - b) / abs(a) for a, b in zip(l_plain, l_grp)) < 1e-12
+assert abs(float(e0) - float(e1)) < 1e-9 * abs(float(e0)) and float((g0 - g1).abs().max()) <= 1e-6 * float(g0.abs().max())
+print("rccl one-rank ok")
+"""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0 and "rccl one-rank ok" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
