@@ -72,7 +72,9 @@ int hode_nn_param_count(int H, int L);
  * interval (bit 30 set when the step ended exactly on the grid point closing that interval), and the "stage tape" -- the
  * MLP activations and stage state of every Runge-Kutta stage (tuned path 6 x (L x 64 + 8) reals per step, generic path
  * 6 x (2L x 64 + 8)), so that the adjoint never re-runs the forward.  This is a memory-for-compute trade sized for
- * 288 GB of HBM: 6.3 KB per step in fp32 for (64,4), i.e. 1.9 MB per trajectory at max_steps = 300.  hode_tape_bytes(.., L) == hode_tape_bytes_hl(.., 64, L). */
+ * 288 GB of HBM: 6.3 KB per step in fp32 for (64,4), i.e. 1.9 MB per trajectory at max_steps = 300.  Tuned shapes: + the
+ * adjoint's gradient rows, min(B, 1024) x (P + 17 reals, padded to a multiple of 64).
+ * hode_tape_bytes(.., L) == hode_tape_bytes_hl(.., 64, L). */
 size_t hode_tape_bytes_hl(int B, int max_steps, int elem_size /* 4 or 8 */, int H, int L);
 size_t hode_tape_bytes(int B, int max_steps, int elem_size /* 4 or 8 */, int L);
 
@@ -119,9 +121,12 @@ int hode_solve_fwd_f64(void *stream, int B, int T, const double *x0, const doubl
 /* ---- K4: reverse-time discrete adjoint of the solve above (no reference counterpart: the
  *      reference detaches the solve; north_star requires it).
  *      gy[B,T,6] = dLoss/dy  ->  gx0[B,6] (written), gnn[n_sets,P] and gode[n_sets,17]
- *      (ACCUMULATED with atomics: zero them first; either may be NULL).  tape: the buffer the forward filled.  It is not
- *      const: the adjoint may use its tail as scratch; what the forward recorded stays intact, the same tape may be
- *      walked again.
+ *      (ACCUMULATED: added to what is there -- zero them first; either may be NULL).  Tuned shapes (H <= 64, L <= 4): no
+ *      floating-point atomics -- every workgroup writes one gradient row into the tail of the tape and a second, fixed-order
+ *      pass adds the rows: the same call gives the same bits (the reference's CPU training is deterministic).  Generic shapes:
+ *      coalesced atomics, reproducible to rounding only.  tape: the buffer the forward filled.  It is not const: the adjoint
+ *      uses its tail (the gradient rows) as scratch; what the forward recorded stays intact, the same tape may be walked
+ *      again.
  *      nsteps[b], status[b]: what the forward returned for this tape.  The adjoint walks min(nsteps[b], max_steps) steps:
  *      a count larger than the tape it is handed (the caller merged the bookkeeping of a re-integration with a larger
  *      budget, say) is CLAMPED SILENTLY -- never an out-of-bounds read, but then the gradient is that of the truncated
