@@ -444,13 +444,17 @@ template <typename R, int NL> static int launch_bwd_nl(hipStream_t s, const AdjA
     return a.gode ? launch_bwd_k<R, NL, true, false>(s, a, method) : launch_bwd_k<R, NL, false, false>(s, a, method);
 }
 
-// HODE_BWD=fused (any build): the one-role kernel also for the fp32 shapes the wave-specialised kernel takes -- A/B timing and
-// the parity test that compares the two (read once per process; not on the product's default path)
+#ifdef HODE_LAB
+// Lab library only.  HODE_BWD=fused: the one-role kernel also for the fp32 shapes the wave-specialised kernel takes -- A/B timing
+// (tools/ws_dbg.sh) and the parity test that compares the two
 static bool bwd_force_fused()
 {
     static const bool v = [] { const char *e = getenv("HODE_BWD"); return e && e[0] == 'f'; }();
     return v;
 }
+#else
+constexpr bool bwd_force_fused() { return false; }
+#endif
 
 template <typename R> int launch_solve_bwd(hipStream_t s, const AdjArgs<R> &a, int L, int method)
 {
