@@ -351,7 +351,7 @@ __global__ __launch_bounds__(64 * kWsWaves) void solve_bwd_ws_kernel(const AdjAr
         // the propagation waves are the critical path of every iteration: they issue first, the accumulation waves fill the gaps
         if (!(dbg & 16)) __builtin_amdgcn_s_setprio(2);
         // edge weights in registers (no accumulators here: there is room); per trajectory: step / stage cursors
-        R w1[9], w5[6];
+        R w1r[8], w5[6];
         OdeP<R> o;
         R lam[U], ZZ[U], tc[U], h[U], t0[U], inv_len[U], v0[U], dv[U], d0[U], dd[U];
         int bi_next[U], b[U], n[U], st[U], s[U], knext[U], k[U], cur[U];
@@ -362,9 +362,22 @@ __global__ __launch_bounds__(64 * kWsWaves) void solve_bwd_ws_kernel(const AdjAr
             const int j = (lane < a.H) ? lane : a.H - 1;
             const R *pout = nn_set + 9 * a.H + a.H + (size_t)NM * ((size_t)a.H * a.H + a.H);
 #pragma unroll
-            for (int i = 0; i < 9; ++i) w1[i] = live * nn_set[j * 9 + i];
-#pragma unroll
             for (int q = 0; q < 6; ++q) w5[q] = live * pout[q * a.H + j];
+            // first-layer weights of the six state inputs in the rotating order of out_rot (hode_device.h): lane (r, i) keeps, for
+            // input o = i & 7, w1r[n] = W1[16 r + ((i - n) & 15)][1 + o] (GLP1, o = 3, feeds inputs 4 and 7; zero for o >= 6), so
+            // that the state cotangent W1^T delta_1 is 8 FMAs on delta_1 in its natural layout + a 7-instruction reduction that
+            // lands in the replicated layout of the state -- 15 instructions instead of six products + the 30 of
+            // wave_reduce6_to_lanes, in a wave whose time is its instruction count
+            const int i16 = lane & 15, r16 = lane >> 4, oin = lane & 7;
+#pragma unroll
+            for (int n_ = 0; n_ < 8; ++n_) {
+                const int ku = 16 * r16 + ((i16 - n_) & 15);
+                const bool okw = oin < 6 && ku < a.H;
+                const int kk = okw ? ku : 0, oo = okw ? oin : 0;
+                R v = nn_set[kk * 9 + 1 + oo];
+                if (oo == 3) v += nn_set[kk * 9 + 7];
+                w1r[n_] = okw ? v : 0.f;
+            }
             ode_load(o, a.ode_p + 17 * set);
             // as VGPRs: 17 wave-uniform SGPRs are more than this loop has (they were spilled to lanes of a VGPR and read back with
             // a v_readlane per use), and a VALU instruction reads one SGPR only -- the state / cotangent broadcasts are SGPRs already
@@ -540,15 +553,9 @@ __global__ __launch_bounds__(64 * kWsWaves) void solve_bwd_ws_kernel(const AdjAr
                 // lanes 0..5 kb, 6 t, 7 tVNS (the other groups of eight: copies, never read): no exec mask.  The tag: every lane writes the same word
                 hd[u][NL * kWave + lane] = (c8 < 6) ? kb[u] : (c8 == 6) ? ts[u] : tv[u];
                 tags[par * 16 + wave * U + u] = active[u] ? 1 + slot[u] : 0;                      // valid, and which ring slot
-                R p[6];
-                p[0] = w1[1] * d[u];
-                p[1] = w1[2] * d[u];
-                p[2] = w1[3] * d[u];
-                p[3] = (w1[4] + w1[7]) * d[u];                 // GLP1 feeds inputs 4 and 7
-                p[4] = w1[5] * d[u];
-                p[5] = w1[6] * d[u];
-                const R nnv = (dbg & 8) ? p[0] + p[1] + p[2] + p[3] + p[4] + p[5] : wave_reduce6_to_lanes(p, lane);
-                const R Z = (c8 < 6) ? (mech[u] + nnv) : 0.f;
+                // W1^T delta_1 on the six state inputs, replicated layout, exact zeros on slots 6, 7 (as the mechanistic part)
+                const R nnv = (dbg & 8) ? d[u] : out_rot(w1r, 0.f, d[u]);
+                const R Z = mech[u] + nnv;
                 if (active[u]) {
                     ZZ[u] = (grp == s[u]) ? Z : ZZ[u];
                     if (s[u] == 0) {
