@@ -36,3 +36,28 @@ def test_committed_pmc_stamp_matches_the_committed_kernels():
     stamp = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["kernel_source_sha"]
     if stamp != bench.kernel_source_sha():      # a reminder, not a gate: kernels may change in a container without a GPU
         pytest.skip("profiles/pmc_traffic.json is stale: re-run tools/profile_gpu.sh + tools/summarize_profile.py on the GPU box")
+
+
+def test_binary_stamp_follows_the_sources(tmp_path, monkeypatch):
+    """csrc/Makefile stamps libhode.so with a hash of its sources; hode/_build.py recomputes it from the tree.  The committed
+    tree's binary is current; any change to a kernel source, a header, the C ABI header or the Makefile makes it stale, and a
+    caller that may not build (bench.py --no-build: everything under rocprofv3) gets an error instead of a stale benchmark."""
+    import pytest
+    from hode import _build
+    assert _build.is_current() and _build.source_stamp() == _build.binary_stamp()
+    pkg = tmp_path / "pkg"
+    shutil.copytree(os.path.join(ROOT, "hybrid-ode-for-glp-1-and-glucose_amd", "csrc"), pkg / "csrc",
+                    ignore=shutil.ignore_patterns("_obj", "*.o", ".build.lock"))
+    os.makedirs(tmp_path / "include")
+    shutil.copy(os.path.join(ROOT, "include", "hode.h"), tmp_path / "include" / "hode.h")
+    os.makedirs(pkg / "hode")
+    shutil.copy(_build.SO, pkg / "hode" / "libhode.so")
+    shutil.copy(_build.SO + ".srcsha", pkg / "hode" / "libhode.so.srcsha")
+    monkeypatch.setattr(_build, "CSRC", str(pkg / "csrc"))
+    monkeypatch.setattr(_build, "SO", str(pkg / "hode" / "libhode.so"))
+    assert _build.is_current()                                        # same sources, other place
+    f = pkg / "csrc" / "hode_optim.hip"
+    f.write_text(f.read_text() + "\n// touched\n")
+    assert not _build.is_current()
+    with pytest.raises(RuntimeError, match="may not start a build"):
+        _build.ensure(may_build=False)
