@@ -1,8 +1,8 @@
 """Forward-kernel tuning points (development aid).  One process per variant (the environment switches are read once):
     (default)                          register-resident kernel (hode_solve_fwd.hip)
-    HODE_FWD=wg HODE_FWD_CFG=<NREG><WPB/4>   workgroup kernel (hode_solve_fwd_wg.hip): 4, 22, default (14)
-    HODE_FWD=quad                      four trajectories per four waves, column-split weights (hode_solve_fwd_quad.hip)
-    HODE_FWD=rows                      four trajectories per four waves, weights split by output rows / input blocks (hode_solve_fwd_rows.hip)
+    HODE_FWD=wg HODE_FWD_CFG=<NREG><WPB/4>   workgroup kernel (csrc/lab/hode_solve_fwd_wg.hip): 4, 22, default (14)
+    HODE_FWD=quad                      four trajectories per four waves, column-split weights (csrc/lab/hode_solve_fwd_quad.hip)
+    HODE_FWD=rows                      four trajectories per four waves, weights split by output rows / input blocks (csrc/lab/hode_solve_fwd_rows.hip)
 Usage: python tools/fwd_variants.py [B ...]   -> one line per batch size; the first run writes /tmp/fwd_ref_<B>.pt, later runs compare bitwise."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
