@@ -430,3 +430,51 @@ def test_cfg5_posterior_predictive_module_function_equals_the_vi_method():
     torch.manual_seed(5)
     m1, s1 = M.compute_posterior_predictive(m, x0[0], t, {k: v[0] for k, v in ext.items()}, n_samples=4)
     assert tuple(m1.shape) == (31, 6) and tuple(s1.shape) == (31, 6)
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# the wave-specialised adjoint's own geometry
+@pytest.mark.parametrize("B", [1, 7, 9, 2100])
+def test_ws_adjoint_slot_geometry_ragged_batches_vs_oracle(hode, B):
+    """csrc/hode_solve_bwd_ws.hip deals trajectories to 8 (or, above 8 per workgroup, 16) slots per workgroup, slot-major, and runs
+    all of them in lock step for as many iterations as the longest slot needs.  Batches that leave slots empty, fill them
+    unevenly (2 100 = 256 workgroups x 8 slots + 52: two trajectories per propagation wave, most second trajectories missing),
+    trajectories of different length in one workgroup (a batched grid with repeated times shortens some), one that fails at
+    row 0 (NaN state: zero steps on the tape) and one whose step budget ends mid-grid: gx0 trajectory by trajectory and the
+    parameter gradient against the fp64 oracle fed the same cotangent."""
+    Tn = 13
+    rng = np.random.default_rng(B)
+    base = np.array([5.0, 60.0, 80.0, 10.0, 0.0, 1.0])
+    x0 = base * (1 + 0.05 * rng.standard_normal((B, 6)))
+    t = np.tile(np.arange(Tn) * (5.0 / 60.0), (B, 1))
+    for b in range(0, B, 5):                               # every fifth trajectory: a shorter grid (repeated times at both ends)
+        t[b, :3] = t[b, 2]
+        t[b, -2:] = t[b, -3]
+    meal = (rng.random((B, Tn)) < 0.2).astype(np.float64)
+    tv = np.zeros((B, Tn))
+    if B >= 7:
+        x0[3, 2] = np.nan                                  # status 3 at row 0
+    nn, ode = bench.synth_weights(0).numpy().astype(np.float64), bench.ODE_DEFAULT.numpy().astype(np.float64)
+    max_steps = Tn - 3 if B == 9 else 2 * Tn               # B = 9: the budget (10 steps for up to 12 intervals) runs out on the full grids
+    s = hode.solve_fwd(dev(x0), dev(t), dev(meal), dev(tv), None, dev(ode), dev(nn), H, L, want_tape=True, max_steps=max_steps)
+    st = s.status.cpu().numpy()
+    c = rng.standard_normal((B, Tn, 6)) / (B * Tn * 6)
+    gx0, gnn, gode = (v.cpu().numpy() for v in hode.solve_bwd(s, dev(c), want_gode=True))
+    with np.errstate(all="ignore"):
+        yo, sto, _, gxo, gno, goo = oracle_fwd_bwd(x0, t, meal, tv, ode, nn, lambda y, lo, hi: c[lo:hi], rtol=1e-6, atol=1e-8, dtype=np.float64,
+                                                   max_steps=max_steps, chunk=64)
+    assert np.array_equal(st, sto), (st, sto)
+    if B == 9:
+        assert (st == 1).sum() >= 5
+    if B >= 7:
+        assert st[3] == 3 and np.allclose(gx0[3], c[3, 0], rtol=1e-6)
+    fin = np.isfinite(gxo).all(axis=1)
+    assert np.all(np.isfinite(gnn)) and np.all(np.isfinite(gode))
+    worst = max(relnorm(gx0[b], gxo[b]) for b in np.nonzero(fin)[0])
+    assert worst < 1e-4, worst
+    assert relnorm(gnn, gno) < 1e-4 and relnorm(gode, goo) < 1e-3
+    gx0b, gnnb, godeb = (v.cpu().numpy() for v in hode.solve_bwd(s, dev(c), want_gode=True))
+    assert np.array_equal(gnn, gnnb) and np.array_equal(gode, godeb) and np.array_equal(gx0[fin], gx0b[fin])      # same bits twice
+    # without ODE-constant gradients the big batch takes the two-trajectories-per-wave instantiation
+    _, gnn2, _ = hode.solve_bwd(s, dev(c))
+    assert relnorm(gnn2.cpu().numpy(), gno) < 1e-4
