@@ -17,6 +17,7 @@
 // linearly with B x T.  The integrator, controller, tape format and state layout are those of the tuned path
 // (hode_solve_body.h); CPU restatement: oracle/hode_oracle_impl.h (HODE_MAXH 128, HODE_MAXL 8).
 #include "hode_solve_body.h"
+#include <type_traits>
 
 namespace hode {
 
@@ -129,10 +130,53 @@ template <typename R, int NW = 1> struct RhsStream {
 // matrix, which are split: wave `part` takes rows [j0, j1) of W^T delta (partial sums exchanged through xch[NW][2][64] in LDS and
 // added in wave order) and of the atomics dW += delta (x) h_in.  A trajectory of such a network is one long chain of L2 round
 // trips; with the batches these shapes are trained on (32 trajectories) one wave per trajectory left 97 % of the chip idle.
-template <typename R, bool GODE, bool GT, int NW = 1>
+// Register accumulators of a team wave for its eight rows of up to kGenAccMats hidden matrices (fp32 adjoint of the solve, H <=
+// 8 NW, L - 1 <= kGenAccMats): dW[j0 + u][lane], dW[j0 + u][lane + 64].  With them the hidden-matrix gradients leave the chip once
+// per workgroup instead of once per stage (280 KB of atomics per stage of the 5 x 128 network: what bound the adjoint above a few
+// hundred trajectories).  NoAcc: the atomics of round 2 (K5, fp64, deeper networks).
+constexpr int kGenAccMats = 4;
+struct NoAcc {};
+struct TeamAcc {
+    float v[kGenAccMats][8][2];
+    __device__ __forceinline__ void zero()
+    {
+#pragma unroll
+        for (int l = 0; l < kGenAccMats; ++l)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[l][u][0] = v[l][u][1] = 0.f;
+    }
+    // v[l] += p (l wave-uniform, 0 .. kGenAccMats - 1: a branch per matrix keeps the accumulators in registers)
+    __device__ __forceinline__ void add(int l, const float (&pa)[8], const float (&pb)[8])
+    {
+#define HODE_ACC_CASE(LL) case LL: _Pragma("unroll") for (int u = 0; u < 8; ++u) { v[LL][u][0] += pa[u]; v[LL][u][1] += pb[u]; } break;
+        switch (l) { HODE_ACC_CASE(0) HODE_ACC_CASE(1) HODE_ACC_CASE(2) default: _Pragma("unroll") for (int u = 0; u < 8; ++u) { v[3][u][0] += pa[u]; v[3][u][1] += pb[u]; } break; }
+#undef HODE_ACC_CASE
+    }
+    // one atomic per entry and WORKGROUP (after all its trajectories of a parameter set)
+    __device__ __forceinline__ void flush(const StreamNet<float> &n, float *__restrict__ g, int j0, int lane)
+    {
+        const int H = n.H;
+        if (g == nullptr) return;
+#pragma unroll
+        for (int l = 0; l < kGenAccMats; ++l) {
+            if (l > n.L - 2) break;
+            float *__restrict__ gW = g + n.hid_off(l);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = j0 + u;
+                if (j < H) {
+                    if (lane < H) atomic_add(gW + (size_t)j * H + lane, v[l][u][0]);
+                    if (lane + 64 < H) atomic_add(gW + (size_t)j * H + lane + 64, v[l][u][1]);
+                }
+            }
+        }
+    }
+};
+
+template <typename R, bool GODE, bool GT, int NW = 1, typename ACC = NoAcc>
 __device__ __forceinline__ R rhs_vjp_stream(const StreamNet<R> &n, R *__restrict__ g, const OdeP<R> &o, R t, R tvns, R gde, R gd_in,
                                             bool use_gd, int lane, const R *__restrict__ rec, R kb, R &go, R *gt_out, int part = 0,
-                                            R *__restrict__ xch = nullptr)
+                                            R *__restrict__ xch = nullptr, ACC *acc = nullptr)
 {
     const int H = n.H, L = n.L;
     const R *__restrict__ sx = rec + 2 * L * kWave;            // the stage state: wave-uniform loads
@@ -207,7 +251,18 @@ __device__ __forceinline__ R rhs_vjp_stream(const StreamNet<R> &n, R *__restrict
             for (int w = 0; w < NW; ++w) { pA += xch[(w * 2 + 0) * kWave + lane]; pB += xch[(w * 2 + 1) * kWave + lane]; }
             __syncthreads();
         }
-        if (g) {
+        if constexpr (std::is_same<ACC, TeamAcc>::value) {
+            if (g) {
+                float pa[8], pb[8];                            // this wave's eight rows of dW += delta (x) h_in (masked lanes: h_in = 0)
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const R dj = (j0 + u < j1) ? unit_bcast(dA, dB, (j0 + u < j1) ? j0 + u : 0) : R(0);
+                    pa[u] = dj * inA;
+                    pb[u] = dj * inB;
+                }
+                acc->add(l, pa, pb);
+            }
+        } else if (g) {
             for (j = j0; j < j1; ++j) {
                 const R dj = unit_bcast(dA, dB, j);
                 if (dj == R(0)) continue;                      // wave-uniform: no atomics for dead units
@@ -359,9 +414,12 @@ template <typename R> int launch_solve_fwd_generic(hipStream_t s, const SolveArg
 // the forward has just written them), gradients leave through atomics inside rhs_vjp_stream.
 // waves per trajectory in the generic adjoint: 16 for H > 64 (eight rows of a 128 x 128 matrix each = one chunk of loads;
 // 32 x 61 of the 5 x 128 network: 22.4 ms with one wave per trajectory, 10.6 with 8, 9.0 with 16), 8 up to H = 64 (4.4 / 5.8 ms)
-template <typename R, bool GODE, bool GD, int kGenTeam>
+template <typename R, bool GODE, bool GD, int kGenTeam, bool ACCREG>
 __global__ __launch_bounds__(64 * kGenTeam) void solve_bwd_generic_kernel(const AdjArgs<R> a, const int method, const int L)
 {
+    using Acc = std::conditional_t<ACCREG, TeamAcc, NoAcc>;
+    Acc acc;
+    int acc_set = -1;                                       // the parameter set the accumulators belong to
     __shared__ R rowsT[8 * kWave];
     __shared__ R xch[kGenTeam * 2 * kWave];
     const int lane = threadIdx.x & 63;
@@ -375,10 +433,19 @@ __global__ __launch_bounds__(64 * kGenTeam) void solve_bwd_generic_kernel(const 
     __syncthreads();
     const int per_set = a.B / a.n_sets;
     constexpr bool use_gd = GD;
+    const int rows_per_k = (((a.H + kGenTeam - 1) / kGenTeam) + 7) & ~7;
+    const int j0_k = (part * rows_per_k < a.H) ? part * rows_per_k : a.H;
     for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
         const int set = b / per_set;
         const StreamNet<R> n{a.nn_p + (size_t)set * a.P, a.H, L};
         R *__restrict__ g = a.gnn ? a.gnn + (size_t)set * a.P : nullptr;
+        if constexpr (ACCREG) {
+            if (set != acc_set) {                           // a workgroup's trajectories come set by set: flush when the set changes
+                if (acc_set >= 0) acc.flush(StreamNet<R>{a.nn_p + (size_t)acc_set * a.P, a.H, L}, a.gnn ? a.gnn + (size_t)acc_set * a.P : nullptr, j0_k, lane);
+                acc.zero();
+                acc_set = set;
+            }
+        }
         OdeP<R> o;
         ode_load(o, a.ode_p + 17 * set);
         const R *__restrict__ tg = a.t + (a.t_batched ? (size_t)b * T : 0);
@@ -422,8 +489,8 @@ __global__ __launch_bounds__(64 * kGenTeam) void solve_bwd_generic_kernel(const 
                 const R gdv = rfma(al, dd, d0);
                 R gde = R(0);
                 if constexpr (use_gd) gde = gd_effect(o, gdv);
-                const R Z = rhs_vjp_stream<R, GODE, false, kGenTeam>(n, g, o, ts, rfma(al, dv, v0), gde, gdv, use_gd, lane,
-                                                                     stg + ((size_t)st * 6 + s) * kSlot, kb, go, nullptr, part, xch);
+                const R Z = rhs_vjp_stream<R, GODE, false, kGenTeam, Acc>(n, g, o, ts, rfma(al, dv, v0), gde, gdv, use_gd, lane,
+                                                                          stg + ((size_t)st * 6 + s) * kSlot, kb, go, nullptr, part, xch, &acc);
                 ZZ = (grp == s) ? Z : ZZ;
             }
             lam += group_sum8(rowsT[7 * kWave + lane] * ZZ);
@@ -438,24 +505,35 @@ __global__ __launch_bounds__(64 * kGenTeam) void solve_bwd_generic_kernel(const 
             }
         }
     }
+    if constexpr (ACCREG) {
+        if (acc_set >= 0) acc.flush(StreamNet<R>{a.nn_p + (size_t)acc_set * a.P, a.H, L}, a.gnn ? a.gnn + (size_t)acc_set * a.P : nullptr, j0_k, lane);
+    }
 }
 
-template <typename R, int NW> static int launch_bwd_generic_t(hipStream_t s, const AdjArgs<R> &a, int L, int method)
+template <typename R, int NW, bool ACCREG> static int launch_bwd_generic_t(hipStream_t s, const AdjArgs<R> &a, int L, int method)
 {
-    const dim3 grid(a.B < 4096 ? a.B : 4096), block(64 * NW);
+    // with register accumulators a workgroup flushes once: fewer, longer-lived workgroups (a few per CU) beat one per trajectory
+    int blocks = a.B < 4096 ? a.B : 4096;
+    if (ACCREG && blocks > 1024) blocks = 1024;
+    const dim3 grid(blocks), block(64 * NW);
     const bool gd = a.gd_mode != 0;
     if (a.gode) {
-        if (gd) hipLaunchKernelGGL((solve_bwd_generic_kernel<R, true, true, NW>), grid, block, 0, s, a, method, L);
-        else hipLaunchKernelGGL((solve_bwd_generic_kernel<R, true, false, NW>), grid, block, 0, s, a, method, L);
+        if (gd) hipLaunchKernelGGL((solve_bwd_generic_kernel<R, true, true, NW, ACCREG>), grid, block, 0, s, a, method, L);
+        else hipLaunchKernelGGL((solve_bwd_generic_kernel<R, true, false, NW, ACCREG>), grid, block, 0, s, a, method, L);
     } else {
-        if (gd) hipLaunchKernelGGL((solve_bwd_generic_kernel<R, false, true, NW>), grid, block, 0, s, a, method, L);
-        else hipLaunchKernelGGL((solve_bwd_generic_kernel<R, false, false, NW>), grid, block, 0, s, a, method, L);
+        if (gd) hipLaunchKernelGGL((solve_bwd_generic_kernel<R, false, true, NW, ACCREG>), grid, block, 0, s, a, method, L);
+        else hipLaunchKernelGGL((solve_bwd_generic_kernel<R, false, false, NW, ACCREG>), grid, block, 0, s, a, method, L);
     }
     return hipGetLastError() == hipSuccess ? HODE_OK : HODE_ELAUNCH;
 }
 template <typename R> int launch_solve_bwd_generic(hipStream_t s, const AdjArgs<R> &a, int L, int method)
 {
-    return a.H > 64 ? launch_bwd_generic_t<R, 16>(s, a, L, method) : launch_bwd_generic_t<R, 8>(s, a, L, method);
+    if constexpr (sizeof(R) == 4) {
+        // fp32, at most kGenAccMats hidden matrices: their gradients accumulate in the team's registers (eight rows per wave)
+        if (L - 1 <= kGenAccMats && a.gnn != nullptr)
+            return a.H > 64 ? launch_bwd_generic_t<R, 16, true>(s, a, L, method) : launch_bwd_generic_t<R, 8, true>(s, a, L, method);
+    }
+    return a.H > 64 ? launch_bwd_generic_t<R, 16, false>(s, a, L, method) : launch_bwd_generic_t<R, 8, false>(s, a, L, method);
 }
 
 template int launch_rhs_fwd_generic<float>(hipStream_t, const RhsArgs<float> &, int);
