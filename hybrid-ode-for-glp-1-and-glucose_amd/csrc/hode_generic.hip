@@ -137,46 +137,58 @@ template <typename R, int NW = 1> struct RhsStream {
 constexpr int kGenAccMats = 4;
 struct NoAcc {};
 struct TeamAcc {
-    float v[kGenAccMats][8][2];
+    // four separate arrays, not one [4][8][2]: hipcc folds a switch over identical case bodies into a dynamically indexed access,
+    // and a dynamically indexed register array lives in scratch
+    float m0[8][2], m1[8][2], m2[8][2], m3[8][2];
     __device__ __forceinline__ void zero()
     {
 #pragma unroll
-        for (int l = 0; l < kGenAccMats; ++l)
-#pragma unroll
-            for (int u = 0; u < 8; ++u) v[l][u][0] = v[l][u][1] = 0.f;
+        for (int u = 0; u < 8; ++u) m0[u][0] = m0[u][1] = m1[u][0] = m1[u][1] = m2[u][0] = m2[u][1] = m3[u][0] = m3[u][1] = 0.f;
     }
-    // v[l] += p (l wave-uniform, 0 .. kGenAccMats - 1: a branch per matrix keeps the accumulators in registers)
+    // matrix l (wave-uniform, 0 .. kGenAccMats - 1) += p
     __device__ __forceinline__ void add(int l, const float (&pa)[8], const float (&pb)[8])
     {
-#define HODE_ACC_CASE(LL) case LL: _Pragma("unroll") for (int u = 0; u < 8; ++u) { v[LL][u][0] += pa[u]; v[LL][u][1] += pb[u]; } break;
-        switch (l) { HODE_ACC_CASE(0) HODE_ACC_CASE(1) HODE_ACC_CASE(2) default: _Pragma("unroll") for (int u = 0; u < 8; ++u) { v[3][u][0] += pa[u]; v[3][u][1] += pb[u]; } break; }
-#undef HODE_ACC_CASE
+        if (l == 0) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { m0[u][0] += pa[u]; m0[u][1] += pb[u]; }
+        } else if (l == 1) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { m1[u][0] += pa[u]; m1[u][1] += pb[u]; }
+        } else if (l == 2) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { m2[u][0] += pa[u]; m2[u][1] += pb[u]; }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { m3[u][0] += pa[u]; m3[u][1] += pb[u]; }
+        }
+    }
+    __device__ __forceinline__ void flush_one(const float (&m)[8][2], float *__restrict__ gW, int H, int j0, int lane)
+    {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int j = j0 + u;
+            if (j < H) {
+                if (lane < H) atomic_add(gW + (size_t)j * H + lane, m[u][0]);
+                if (lane + 64 < H) atomic_add(gW + (size_t)j * H + lane + 64, m[u][1]);
+            }
+        }
     }
     // one atomic per entry and WORKGROUP (after all its trajectories of a parameter set)
     __device__ __forceinline__ void flush(const StreamNet<float> &n, float *__restrict__ g, int j0, int lane)
     {
-        const int H = n.H;
         if (g == nullptr) return;
-#pragma unroll
-        for (int l = 0; l < kGenAccMats; ++l) {
-            if (l > n.L - 2) break;
-            float *__restrict__ gW = g + n.hid_off(l);
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int j = j0 + u;
-                if (j < H) {
-                    if (lane < H) atomic_add(gW + (size_t)j * H + lane, v[l][u][0]);
-                    if (lane + 64 < H) atomic_add(gW + (size_t)j * H + lane + 64, v[l][u][1]);
-                }
-            }
-        }
+        const int nm = n.L - 1;
+        if (nm > 0) flush_one(m0, g + n.hid_off(0), n.H, j0, lane);
+        if (nm > 1) flush_one(m1, g + n.hid_off(1), n.H, j0, lane);
+        if (nm > 2) flush_one(m2, g + n.hid_off(2), n.H, j0, lane);
+        if (nm > 3) flush_one(m3, g + n.hid_off(3), n.H, j0, lane);
     }
 };
 
 template <typename R, bool GODE, bool GT, int NW = 1, typename ACC = NoAcc>
 __device__ __forceinline__ R rhs_vjp_stream(const StreamNet<R> &n, R *__restrict__ g, const OdeP<R> &o, R t, R tvns, R gde, R gd_in,
-                                            bool use_gd, int lane, const R *__restrict__ rec, R kb, R &go, R *gt_out, int part = 0,
-                                            R *__restrict__ xch = nullptr, ACC *acc = nullptr)
+                                            bool use_gd, int lane, const R *__restrict__ rec, R kb, R &go, R *gt_out, int part,
+                                            R *__restrict__ xch, ACC &acc)
 {
     const int H = n.H, L = n.L;
     const R *__restrict__ sx = rec + 2 * L * kWave;            // the stage state: wave-uniform loads
@@ -260,7 +272,7 @@ __device__ __forceinline__ R rhs_vjp_stream(const StreamNet<R> &n, R *__restrict
                     pa[u] = dj * inA;
                     pb[u] = dj * inB;
                 }
-                acc->add(l, pa, pb);
+                acc.add(l, pa, pb);
             }
         } else if (g) {
             for (j = j0; j < j1; ++j) {
@@ -329,7 +341,8 @@ __global__ __launch_bounds__(256) void rhs_bwd_generic_kernel(const RhsArgs<R> a
         (void)rhs_stream<R>(n, o, t, Y, a.meal ? a.meal[s] : R(0), tvns, gde, lane, rec);
         __builtin_amdgcn_wave_barrier();
         R gt;
-        const R Z = rhs_vjp_stream<R, GODE, true>(n, a.gnn, o, t, tvns, gde, gdv, a.gd != nullptr, lane, rec, kb, go, &gt);
+        NoAcc na;
+        const R Z = rhs_vjp_stream<R, GODE, true>(n, a.gnn, o, t, tvns, gde, gdv, a.gd != nullptr, lane, rec, kb, go, &gt, 0, (R *)nullptr, na);
         __builtin_amdgcn_wave_barrier();
         if (lane < 6) a.gx[(size_t)s * 6 + lane] = Z;
         if (a.gt && lane == 0) a.gt[s] = gt;
@@ -490,7 +503,7 @@ __global__ __launch_bounds__(64 * kGenTeam) void solve_bwd_generic_kernel(const 
                 R gde = R(0);
                 if constexpr (use_gd) gde = gd_effect(o, gdv);
                 const R Z = rhs_vjp_stream<R, GODE, false, kGenTeam, Acc>(n, g, o, ts, rfma(al, dv, v0), gde, gdv, use_gd, lane,
-                                                                          stg + ((size_t)st * 6 + s) * kSlot, kb, go, nullptr, part, xch, &acc);
+                                                                          stg + ((size_t)st * 6 + s) * kSlot, kb, go, nullptr, part, xch, acc);
                 ZZ = (grp == s) ? Z : ZZ;
             }
             lam += group_sum8(rowsT[7 * kWave + lane] * ZZ);
