@@ -106,7 +106,7 @@ int rhs_bwd(void *stream, int B, const R *x, const R *t, const R *meal, const R 
 
 extern "C" {
 
-const char *hode_version(void) { return "hode 0.2.0 (gfx950; wave-per-trajectory DP5(4) + adjoint; MLP up to 8 x 128)"; }
+const char *hode_version(void) { return "hode 0.3.0 (gfx950; wave-per-trajectory DP5(4) + wave-specialised adjoint; MLP up to 8 x 128)"; }
 
 int hode_nn_param_count(int H, int L) { return (H < 1 || L < 1) ? HODE_EINVAL : nn_param_count(H, L); }
 

@@ -542,8 +542,10 @@ template <typename R, int NW, bool ACCREG> static int launch_bwd_generic_t(hipSt
 template <typename R> int launch_solve_bwd_generic(hipStream_t s, const AdjArgs<R> &a, int L, int method)
 {
     if constexpr (sizeof(R) == 4) {
-        // fp32, at most kGenAccMats hidden matrices: their gradients accumulate in the team's registers (eight rows per wave)
-        if (L - 1 <= kGenAccMats && a.gnn != nullptr)
+        // fp32, at most kGenAccMats hidden matrices: their gradients accumulate in the team's registers (eight rows per wave).
+        // Measured (5 x 128 / 5 x 64, T = 61): B = 32: 8.5 against 9.0 ms / 5.8 against 4.4; B = 256: 23.6 against 31.2 / 22.2
+        // against 24.9; B = 1 024: 91 against 135 / 87 against 99 -- the narrow network at the reference's batch keeps the atomics
+        if (L - 1 <= kGenAccMats && a.gnn != nullptr && (a.H > 64 || a.B > 128))
             return a.H > 64 ? launch_bwd_generic_t<R, 16, true>(s, a, L, method) : launch_bwd_generic_t<R, 8, true>(s, a, L, method);
     }
     return a.H > 64 ? launch_bwd_generic_t<R, 16, false>(s, a, L, method) : launch_bwd_generic_t<R, 8, false>(s, a, L, method);
