@@ -14,7 +14,7 @@
 //                            share every 16-byte read of the transposed matrices.  Per stage and trajectory: record (h_1..h_NL,
 //                            stage state) by LDS-DMA, kb, mechanistic J^T, delta_NL .. delta_1 through the transposed matrices
 //                            (LDS image, rotating-operand order).  No gradient accumulators.  Publishes delta_1..delta_NL, kb,
-//                            t, tVNS in an LDS hand-off slot (1.1 KB per trajectory, double buffered).
+//                            t, tVNS in an LDS hand-off slot (1.25 KB per trajectory, double buffered).
 //   A  8 accumulation waves  A_j owns dW of hidden matrix j % (NL-1) -- 64 accumulators -- for its share of the 8 U trajectory
 //                            slots: dW_m += delta_{m+1} (x) h_m, 64 v_fmac_f32_dpp per slot and stage, operands straight
 //                            from LDS (the slot's record and hand-off), + the bias of that layer; A_4..A_7 also keep the
