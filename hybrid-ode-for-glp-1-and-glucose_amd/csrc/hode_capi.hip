@@ -24,7 +24,8 @@ int solve_fwd(void *stream, int B, int T, const R *x0, const R *t, int t_batched
     if (n_sets < 1 || (B % n_sets) != 0 || max_steps < 1) return HODE_EINVAL;
     if (method != HODE_METHOD_DP54 && method != HODE_METHOD_RK4) return HODE_EINVAL;
     if (!(rtol >= 0) || !(atol >= 0) || (method == HODE_METHOD_DP54 && rtol == 0 && atol == 0)) return HODE_EINVAL;
-    if (H < 1 || H > HODE_MAX_HIDDEN || L < 1 || L > HODE_MAX_LAYERS) return HODE_EUNSUPPORTED;
+    if (H < 1 || H > HODE_MAX_HIDDEN || layers_of(L) < 1 || layers_of(L) > HODE_MAX_LAYERS || act_of(L) > HODE_ACT_LEAKY_RELU || (L >> 16) != 0)
+        return HODE_EUNSUPPORTED;
     if (B == 0) return HODE_OK;
     SolveArgs<R> a;
     a.B = B; a.T = T; a.t_batched = t_batched ? 1 : 0;
@@ -36,9 +37,10 @@ int solve_fwd(void *stream, int B, int T, const R *x0, const R *t, int t_batched
     a.tape = (R *)tape;
     a.tape_seg = tape ? (int32_t *)((char *)tape + tape_seg_offset(B, max_steps, sizeof(R))) : nullptr;
     a.tape_stage = tape ? (R *)((char *)tape + tape_stage_offset(B, max_steps, sizeof(R))) : nullptr;
-    a.L = L;
+    a.L = layers_of(L);
+    a.act = act_of(L);
     if (!tuned_shape(H, L)) return launch_solve_fwd_generic<R>((hipStream_t)stream, a, method);
-    return launch_solve_fwd<R>((hipStream_t)stream, a, L, method);
+    return launch_solve_fwd<R>((hipStream_t)stream, a, layers_of(L), method);
 }
 
 template <typename R>
@@ -47,13 +49,15 @@ int rhs_fwd(void *stream, int B, const R *x, const R *t, const R *meal, const R 
 {
     if (B == 0) return HODE_OK;
     if (B < 0 || !x || !ode_p || !nn_p || !out) return HODE_EINVAL;
-    if (H < 1 || H > HODE_MAX_HIDDEN || L < 1 || L > HODE_MAX_LAYERS) return HODE_EUNSUPPORTED;
+    if (H < 1 || H > HODE_MAX_HIDDEN || layers_of(L) < 1 || layers_of(L) > HODE_MAX_LAYERS || act_of(L) > HODE_ACT_LEAKY_RELU || (L >> 16) != 0)
+        return HODE_EUNSUPPORTED;
     if (B == 0) return HODE_OK;
     RhsArgs<R> a{};
     a.B = B; a.H = H; a.P = nn_param_count(H, L);
     a.x = x; a.t = t; a.meal = meal; a.tvns = tvns; a.gd = gd; a.ode_p = ode_p; a.nn_p = nn_p; a.out = out;
-    if (!tuned_shape(H, L)) return launch_rhs_fwd_generic<R>((hipStream_t)stream, a, L);
-    return launch_rhs_fwd<R>((hipStream_t)stream, a, L);
+    a.act = act_of(L);
+    if (!tuned_shape(H, L)) return launch_rhs_fwd_generic<R>((hipStream_t)stream, a, layers_of(L));
+    return launch_rhs_fwd<R>((hipStream_t)stream, a, layers_of(L));
 }
 
 template <typename R>
@@ -67,7 +71,8 @@ int solve_bwd(void *stream, int B, int T, const R *t, int t_batched, const R *me
     if (!mode_ok(meal_mode, meal) || !mode_ok(tvns_mode, tvns) || !mode_ok(gd_mode, gd)) return HODE_EINVAL;
     if (n_sets < 1 || (B % n_sets) != 0 || max_steps < 1) return HODE_EINVAL;
     if (method != HODE_METHOD_DP54 && method != HODE_METHOD_RK4) return HODE_EINVAL;
-    if (H < 1 || H > HODE_MAX_HIDDEN || L < 1 || L > HODE_MAX_LAYERS) return HODE_EUNSUPPORTED;
+    if (H < 1 || H > HODE_MAX_HIDDEN || layers_of(L) < 1 || layers_of(L) > HODE_MAX_LAYERS || act_of(L) > HODE_ACT_LEAKY_RELU || (L >> 16) != 0)
+        return HODE_EUNSUPPORTED;
     if (B == 0) return HODE_OK;
     AdjArgs<R> a;
     a.B = B; a.T = T; a.t_batched = t_batched ? 1 : 0;
@@ -82,8 +87,9 @@ int solve_bwd(void *stream, int B, int T, const R *t, int t_batched, const R *me
     a.tape_delta = has_delta_tape(sizeof(R), H, L) ? (R *)((char *)tape + tape_delta_offset(B, max_steps, sizeof(R), H, L)) : nullptr;
     a.partials = tuned_shape(H, L) ? (R *)((char *)tape + tape_partials_offset(B, max_steps, sizeof(R), H, L)) : nullptr;
     a.partial_rows = adj_partial_rows(B);
-    if (!tuned_shape(H, L)) return launch_solve_bwd_generic<R>((hipStream_t)stream, a, L, method);
-    return launch_solve_bwd<R>((hipStream_t)stream, a, L, method);
+    a.act = act_of(L);
+    if (!tuned_shape(H, L)) return launch_solve_bwd_generic<R>((hipStream_t)stream, a, layers_of(L), method);
+    return launch_solve_bwd<R>((hipStream_t)stream, a, layers_of(L), method);
 }
 
 template <typename R>
@@ -92,14 +98,16 @@ int rhs_bwd(void *stream, int B, const R *x, const R *t, const R *meal, const R 
 {
     if (B == 0) return HODE_OK;
     if (B < 0 || !x || !ode_p || !nn_p || !gout || !gx) return HODE_EINVAL;
-    if (H < 1 || H > HODE_MAX_HIDDEN || L < 1 || L > HODE_MAX_LAYERS) return HODE_EUNSUPPORTED;
+    if (H < 1 || H > HODE_MAX_HIDDEN || layers_of(L) < 1 || layers_of(L) > HODE_MAX_LAYERS || act_of(L) > HODE_ACT_LEAKY_RELU || (L >> 16) != 0)
+        return HODE_EUNSUPPORTED;
     if (B == 0) return HODE_OK;
     RhsArgs<R> a{};
     a.B = B; a.H = H; a.P = nn_param_count(H, L);
     a.x = x; a.t = t; a.meal = meal; a.tvns = tvns; a.gd = gd; a.ode_p = ode_p; a.nn_p = nn_p;
     a.gout = gout; a.gx = gx; a.gt = gt; a.gnn = gnn; a.gode = gode;
-    if (!tuned_shape(H, L)) return launch_rhs_bwd_generic<R>((hipStream_t)stream, a, L);
-    return launch_rhs_bwd<R>((hipStream_t)stream, a, L);
+    a.act = act_of(L);
+    if (!tuned_shape(H, L)) return launch_rhs_bwd_generic<R>((hipStream_t)stream, a, layers_of(L));
+    return launch_rhs_bwd<R>((hipStream_t)stream, a, layers_of(L));
 }
 
 }  // namespace
@@ -108,7 +116,7 @@ extern "C" {
 
 const char *hode_version(void) { return "hode 0.3.0 (gfx950; wave-per-trajectory DP5(4) + wave-specialised adjoint; MLP up to 8 x 128)"; }
 
-int hode_nn_param_count(int H, int L) { return (H < 1 || L < 1) ? HODE_EINVAL : nn_param_count(H, L); }
+int hode_nn_param_count(int H, int L) { return (H < 1 || layers_of(L) < 1) ? HODE_EINVAL : nn_param_count(H, L); }
 
 size_t hode_tape_bytes_hl(int B, int max_steps, int elem_size, int H, int L)
 {

@@ -258,7 +258,7 @@ template <typename R, int NL> struct MlpRegs {
 template <typename T, typename = void> struct applies_relu { static constexpr bool value = false; };
 template <typename T> struct applies_relu<T, decltype((void)T::kHiddenRelu)> { static constexpr bool value = T::kHiddenRelu; };
 
-__host__ __device__ inline int nn_param_count(int H, int L) { return 9 * H + H + (L - 1) * (H * H + H) + 6 * H + 6; }
+__host__ __device__ inline int nn_param_count(int H, int L) { L &= 0xff; return 9 * H + H + (L - 1) * (H * H + H) + 6 * H + 6; }   // (L may carry an activation code in bits 8..15)
 
 // fp32 hidden layers use the "rotating operand" form (see mlp_hidden): register r = 16q + n of lane j holds
 // W_l[j][16q + ((j - n) & 15)], so that the activation can be fetched with a DPP row_ror:n operand of

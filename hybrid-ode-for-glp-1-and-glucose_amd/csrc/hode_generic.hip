@@ -22,9 +22,35 @@
 namespace hode {
 
 // one parameter set in the flat PyTorch parameters() layout (include/hode.h)
+// activation (wave-uniform code, include/hode.h HODE_ACT_*) and "cotangent times its derivative" from the POST-activation value:
+// h > 0 iff the pre-activation is > 0 for all four; ELU'(x <= 0) = exp(x) = h + 1  (torch: nn.ReLU / Tanh / ELU / LeakyReLU(0.1),
+// reference models/nn_residual.py:50-56)
+__device__ __forceinline__ float act_f(float s, int act)
+{
+    if (act == HODE_ACT_RELU) return rmax0(s);
+    if (act == HODE_ACT_TANH) return tanhf(s);
+    if (act == HODE_ACT_ELU) return s > 0.f ? s : expm1f(s);
+    return s > 0.f ? s : 0.1f * s;
+}
+__device__ __forceinline__ double act_f(double s, int act)
+{
+    if (act == HODE_ACT_RELU) return rmax0(s);
+    if (act == HODE_ACT_TANH) return tanh(s);
+    if (act == HODE_ACT_ELU) return s > 0.0 ? s : expm1(s);
+    return s > 0.0 ? s : 0.1 * s;
+}
+template <typename R> __device__ __forceinline__ R act_bwd(R d, R h, int act)
+{
+    if (act == HODE_ACT_RELU) return h > R(0) ? d : R(0);            // (a select, not a product: 0 * inf stays 0)
+    if (act == HODE_ACT_TANH) return d * (R(1) - h * h);
+    if (act == HODE_ACT_ELU) return h > R(0) ? d : d * (h + R(1));
+    return h > R(0) ? d : R(0.1) * d;
+}
+
 template <typename R> struct StreamNet {
     const R *p;
     int H, L;
+    int act = HODE_ACT_RELU;
     __device__ __forceinline__ const R *W1() const { return p; }                       // [H][9]
     __device__ __forceinline__ const R *b1() const { return p + 9 * H; }
     __device__ __forceinline__ size_t hid_off(int l) const { return (size_t)9 * H + H + (size_t)l * ((size_t)H * H + H); }
@@ -61,8 +87,8 @@ __device__ __forceinline__ R rhs_stream(const StreamNet<R> &n, const OdeP<R> &o,
         hA = rfma(n.W1()[jA * 9 + i], in[i], hA);
         hB = rfma(n.W1()[jB * 9 + i], in[i], hB);
     }
-    hA = vA ? rmax0(hA) : R(0);
-    hB = vB ? rmax0(hB) : R(0);
+    hA = vA ? act_f(hA, n.act) : R(0);
+    hB = vB ? act_f(hB, n.act) : R(0);
     if (rec) { rec[lane] = hA; rec[kWave + lane] = hB; }
     const int cols_per = (((H + NW - 1) / NW) + 7) & ~7;             // this wave's columns: a multiple of 8 (the chunked loads)
     const int k0 = (part * cols_per < H) ? part * cols_per : H, k1 = (k0 + cols_per < H) ? k0 + cols_per : H;
@@ -97,8 +123,8 @@ __device__ __forceinline__ R rhs_stream(const StreamNet<R> &n, const OdeP<R> &o,
             for (int w = 0; w < NW; ++w) { aA += xch[(w * 2 + 0) * kWave + lane]; aB += xch[(w * 2 + 1) * kWave + lane]; }
             __syncthreads();
         }
-        hA = vA ? rmax0(aA) : R(0);
-        hB = vB ? rmax0(aB) : R(0);
+        hA = vA ? act_f(aA, n.act) : R(0);
+        hB = vB ? act_f(aB, n.act) : R(0);
         if (rec) { rec[(2 * (l + 1)) * kWave + lane] = hA; rec[(2 * (l + 1) + 1) * kWave + lane] = hB; }
     }
     R p[6];
@@ -215,8 +241,8 @@ __device__ __forceinline__ R rhs_vjp_stream(const StreamNet<R> &n, R *__restrict
         }
     }
     if (gedge && lane < 6) atomic_add(gedge + n.out_off() + 6 * H + lane, kb);
-    dA = (vA && hA > R(0)) ? dA : R(0);
-    dB = (vB && hB > R(0)) ? dB : R(0);
+    dA = vA ? act_bwd(dA, hA, n.act) : R(0);
+    dB = vB ? act_bwd(dB, hB, n.act) : R(0);
     // hidden matrices, last to first: matrix l maps h_l (rows 2l, 2l+1 of the record) to h_{l+1}
     for (int l = L - 2; l >= 0; --l) {
         const R inA = rec[(2 * l) * kWave + lane], inB = rec[(2 * l + 1) * kWave + lane];
@@ -282,8 +308,8 @@ __device__ __forceinline__ R rhs_vjp_stream(const StreamNet<R> &n, R *__restrict
                 if (vB) atomic_add(gW + (size_t)j * H + jB, dj * inB);
             }
         }
-        dA = (vA && inA > R(0)) ? pA : R(0);
-        dB = (vB && inB > R(0)) ? pB : R(0);
+        dA = vA ? act_bwd(pA, inA, n.act) : R(0);
+        dB = vB ? act_bwd(pB, inB, n.act) : R(0);
     }
     // first layer: input row [t, G, I, Glu, GLP1, GE, FFA, glp1 := GLP1, tvns]
     const R in[9] = {t, G, I, Glu, GLP1, GE, FFA, GLP1, tvns};
@@ -311,7 +337,7 @@ __global__ __launch_bounds__(256) void rhs_fwd_generic_kernel(const RhsArgs<R> a
 {
     const int lane = threadIdx.x & 63;
     const int wave = first_lane((int)(threadIdx.x >> 6));
-    const StreamNet<R> n{a.nn_p, a.H, L};
+    const StreamNet<R> n{a.nn_p, a.H, L, a.act};
     OdeP<R> o;
     ode_load(o, a.ode_p);
     for (int s = blockIdx.x * 4 + wave; s < a.B; s += gridDim.x * 4) {
@@ -329,7 +355,7 @@ __global__ __launch_bounds__(256) void rhs_bwd_generic_kernel(const RhsArgs<R> a
     const int lane = threadIdx.x & 63;
     const int wave = first_lane((int)(threadIdx.x >> 6));
     R *rec = reinterpret_cast<R *>(smem_raw) + (size_t)wave * (2 * L * kWave + 8);      // this wave's record
-    const StreamNet<R> n{a.nn_p, a.H, L};
+    const StreamNet<R> n{a.nn_p, a.H, L, a.act};
     OdeP<R> o;
     ode_load(o, a.ode_p);
     R go = R(0);
@@ -393,7 +419,7 @@ __global__ __launch_bounds__(64 * NW) void solve_fwd_generic_kernel(const SolveA
     OdeP<R> o;
     ode_load(o, a.ode_p + 17 * set);
     __syncthreads();
-    const RhsStream<R, NW> rhs{StreamNet<R>{a.nn_p + (size_t)set * a.P, a.H, a.L}, o, lane, part, xch};
+    const RhsStream<R, NW> rhs{StreamNet<R>{a.nn_p + (size_t)set * a.P, a.H, a.L, a.act}, o, lane, part, xch};
     solve_one<R, METHOD, TAPE, GD>(a, b, rhs, o, rows, cvec, ybuf + part * (kWave + 8), lane);
 }
 
@@ -450,11 +476,11 @@ __global__ __launch_bounds__(64 * kGenTeam) void solve_bwd_generic_kernel(const 
     const int j0_k = (part * rows_per_k < a.H) ? part * rows_per_k : a.H;
     for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
         const int set = b / per_set;
-        const StreamNet<R> n{a.nn_p + (size_t)set * a.P, a.H, L};
+        const StreamNet<R> n{a.nn_p + (size_t)set * a.P, a.H, L, a.act};
         R *__restrict__ g = a.gnn ? a.gnn + (size_t)set * a.P : nullptr;
         if constexpr (ACCREG) {
             if (set != acc_set) {                           // a workgroup's trajectories come set by set: flush when the set changes
-                if (acc_set >= 0) acc.flush(StreamNet<R>{a.nn_p + (size_t)acc_set * a.P, a.H, L}, a.gnn ? a.gnn + (size_t)acc_set * a.P : nullptr, j0_k, lane);
+                if (acc_set >= 0) acc.flush(StreamNet<R>{a.nn_p + (size_t)acc_set * a.P, a.H, L, a.act}, a.gnn ? a.gnn + (size_t)acc_set * a.P : nullptr, j0_k, lane);
                 acc.zero();
                 acc_set = set;
             }
@@ -519,7 +545,7 @@ __global__ __launch_bounds__(64 * kGenTeam) void solve_bwd_generic_kernel(const 
         }
     }
     if constexpr (ACCREG) {
-        if (acc_set >= 0) acc.flush(StreamNet<R>{a.nn_p + (size_t)acc_set * a.P, a.H, L}, a.gnn ? a.gnn + (size_t)acc_set * a.P : nullptr, j0_k, lane);
+        if (acc_set >= 0) acc.flush(StreamNet<R>{a.nn_p + (size_t)acc_set * a.P, a.H, L, a.act}, a.gnn ? a.gnn + (size_t)acc_set * a.P : nullptr, j0_k, lane);
     }
 }
 

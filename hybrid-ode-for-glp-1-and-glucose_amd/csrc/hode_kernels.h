@@ -15,7 +15,8 @@ template <typename R> struct SolveArgs {
     R *tape;            // [B][max_steps][8] = {t, h, y0..y5}
     int32_t *tape_seg;  // [B][max_steps] grid interval of each accepted step (| kSegClosed)
     R *tape_stage;      // [B][max_steps][6 stages][tape_slot_elems]: layer activations + stage state of every accepted step
-    int L;
+    int L;              // hidden layers (plain count)
+    int act;            // HODE_ACT_* (generic kernels; the tuned ones are ReLU)
 };
 
 template <typename R> struct AdjArgs {
@@ -30,6 +31,7 @@ template <typename R> struct AdjArgs {
     R *tape_delta;      // fp32 tuned shapes: [B][max_steps][6][delta_slot_elems] scratch of the split adjoint (part of the tape)
     R *partials;        // tuned shapes: [adj_partial_rows(B)][adj_partial_rowlen(P)] per-workgroup gradient sums (tail of the tape)
     int partial_rows;
+    int act;            // HODE_ACT_* (generic kernels)
 };
 
 template <typename R> struct RhsArgs {
@@ -38,6 +40,7 @@ template <typename R> struct RhsArgs {
     R *out;                 // fwd
     const R *gout;          // bwd
     R *gx, *gt, *gnn, *gode;
+    int act;                // HODE_ACT_* (generic kernels)
 };
 
 template <typename R> int launch_solve_fwd(hipStream_t s, const SolveArgs<R> &a, int L, int method);
@@ -61,7 +64,11 @@ template <typename R> int launch_solve_bwd_generic(hipStream_t s, const AdjArgs<
 template <typename R> int launch_rhs_fwd_generic(hipStream_t s, const RhsArgs<R> &a, int L);
 template <typename R> int launch_rhs_bwd_generic(hipStream_t s, const RhsArgs<R> &a, int L);
 // shapes the tuned (register-resident) kernels are compiled for; everything else up to HODE_MAX_* takes the generic path
-inline bool tuned_shape(int H, int L) { return H <= 64 && L <= 4; }
+// The `L` argument of the C ABI carries the number of hidden layers in bits 0..7 and the activation (HODE_ACT_*) in bits 8..15.
+inline int layers_of(int L) { return L & 0xff; }
+inline int act_of(int L) { return (L >> 8) & 0xff; }
+// (ReLU only: every other activation takes the generic kernels whatever the shape)
+inline bool tuned_shape(int H, int L) { return act_of(L) == HODE_ACT_RELU && H <= 64 && layers_of(L) <= 4; }
 int launch_adam(hipStream_t s, int64_t n, float *p, const float *g, float *m, float *v, float lr, float b1,
                 float b2, float eps, int step, float max_norm, float grad_scale, float wd, void *scratch);
 int launch_mse(hipStream_t s, int64_t n, const float *y, const float *obs, float scale, double *loss, float *gy);
@@ -113,7 +120,7 @@ inline size_t tape_stage_offset(int B, int max_steps, size_t elem)
 }
 // reals per stage record: h_1..h_L (tuned path: L rows of 64; generic path: 2 L rows, two hidden units per lane) + 8 for the
 // stage state
-inline size_t tape_slot_elems(int H, int L) { return (size_t)(tuned_shape(H, L) ? L : 2 * L) * 64 + 8; }
+inline size_t tape_slot_elems(int H, int L) { return (size_t)(tuned_shape(H, L) ? layers_of(L) : 2 * layers_of(L)) * 64 + 8; }
 // The split adjoint of the tuned fp32 path (lab/hode_solve_bwd_split.hip; lab library only, HODE_BWD=split) hands the layer
 // cotangents of every stage from its propagation kernel to its accumulation kernel through HBM: delta_1..delta_L (L rows of
 // 64) + {kb[6], t, tVNS} in 8 reals per stage, in a region of the tape behind the stage tape (the tape is the adjoint's
@@ -125,7 +132,7 @@ bool split_adjoint_enabled();       // HODE_BWD=split (hode_solve_bwd.hip); the 
 #else
 constexpr bool split_adjoint_enabled() { return false; }
 #endif
-inline bool has_delta_tape(size_t elem, int H, int L) { return elem == 4 && tuned_shape(H, L) && L >= 2 && split_adjoint_enabled(); }
+inline bool has_delta_tape(size_t elem, int H, int L) { return elem == 4 && tuned_shape(H, L) && layers_of(L) >= 2 && split_adjoint_enabled(); }
 inline size_t tape_delta_offset(int B, int max_steps, size_t elem, int H, int L)
 {
     size_t o = tape_stage_offset(B, max_steps, elem) + (size_t)B * max_steps * 6 * tape_slot_elems(H, L) * elem;
@@ -149,7 +156,7 @@ inline size_t tape_total_bytes(int B, int max_steps, size_t elem, int H, int L)
 {
     const size_t o = tape_partials_offset(B, max_steps, elem, H, L);
     if (!tuned_shape(H, L)) return o;            // the generic path flushes coalesced atomics (hode_generic.hip)
-    const int P = 9 * H + H + (L - 1) * (H * H + H) + 6 * H + 6;
+    const int P = 9 * H + H + (layers_of(L) - 1) * (H * H + H) + 6 * H + 6;
     return o + (size_t)adj_partial_rows(B) * adj_partial_rowlen(P) * elem;
 }
 #ifdef HODE_LAB

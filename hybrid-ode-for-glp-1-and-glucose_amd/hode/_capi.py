@@ -13,7 +13,7 @@ METHOD_DP54 = 0
 METHOD_RK4 = 1
 
 ST_OK, ST_MAXSTEPS, ST_UNDERFLOW, ST_NONFINITE = 0, 1, 2, 3
-_ERR = {-1: "HODE_EINVAL (bad argument)", -2: "HODE_EUNSUPPORTED (shape outside the supported range: H<=128, L<=8)",
+_ERR = {-1: "HODE_EINVAL (bad argument)", -2: "HODE_EUNSUPPORTED (shape outside the supported range: H<=128, L<=8, activation code <= 3)",
         -3: "HODE_ELAUNCH (HIP launch failed)"}
 
 # every symbol include/hode.h declares (tests check that the library exports all of them)
@@ -58,7 +58,16 @@ def version():
     return load().hode_version().decode()
 
 
+ACT_RELU, ACT_TANH, ACT_ELU, ACT_LEAKY_RELU = 0, 1, 2, 3
+
+
+def layers(L, act=ACT_RELU):
+    """The `L` argument of the C ABI: hidden layers in bits 0..7, activation code in bits 8..15 (include/hode.h HODE_LAYERS)."""
+    return (L & 0xff) | (act << 8)
+
+
 def n_params(H, L):
+    L &= 0xff                                  # (L may carry an activation code)
     return 9 * H + H + (L - 1) * (H * H + H) + 6 * H + 6
 
 

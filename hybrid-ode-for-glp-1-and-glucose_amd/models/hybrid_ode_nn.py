@@ -396,8 +396,8 @@ class HybridODENN(nn.Module):
     # ------------------------------------------------------------------ plumbing
     def _check_supported(self):
         if not self.nn_residual.hip_supported():
-            raise NotImplementedError("the HIP path computes a ReLU MLP 9 -> (<=128) x (1..8) -> 6 without dropout "
-                                      "(include/hode.h); other NNResidual configurations are outside the hot path")
+            raise NotImplementedError("the HIP path computes an MLP 9 -> (<=128) x (1..8) -> 6 with relu / tanh / elu / leaky_relu and "
+                                      "without dropout (include/hode.h); other NNResidual configurations are outside the hot path")
 
     def _params_on(self, dev, params: Optional[Dict[str, torch.Tensor]] = None):
         """(nn_flat, ode_vec) on the compute device; `params` optionally overrides named entries
@@ -437,7 +437,7 @@ class HybridODENN(nn.Module):
         meal, tvns, gd = (self._input(external_inputs, k, dev, n) for k in ("meal", "tVNS", "GD"))
         nn_flat, ode_vec = self._params_on(dev)
         nl = self.nn_residual
-        out = _RhsFn.apply(x.contiguous(), tt.contiguous(), nn_flat, ode_vec, meal, tvns, gd, nl.hidden_dim, nl.n_layers)
+        out = _RhsFn.apply(x.contiguous(), tt.contiguous(), nn_flat, ode_vec, meal, tvns, gd, nl.hidden_dim, nl.hip_layers)
         out = out.to(state.device)
         return out.squeeze(0) if single else out
 
@@ -484,11 +484,11 @@ class HybridODENN(nn.Module):
         nl = self.nn_residual
         if diff and torch.is_grad_enabled():
             y = _SolveFn.apply(x0.contiguous(), nn_flat, ode_vec, t, ins["meal"], ins["tVNS"], ins["GD"],
-                               nl.hidden_dim, nl.n_layers, method, float(rtol), float(atol), n_sets, info, self.tape_steps)
+                               nl.hidden_dim, nl.hip_layers, method, float(rtol), float(atol), n_sets, info, self.tape_steps)
         else:
             with torch.no_grad():
                 sol = hode.solve_fwd(x0.contiguous(), t, ins["meal"], ins["tVNS"], ins["GD"], ode_vec.detach(),
-                                     nn_flat.detach(), nl.hidden_dim, nl.n_layers, method=method, rtol=float(rtol),
+                                     nn_flat.detach(), nl.hidden_dim, nl.hip_layers, method=method, rtol=float(rtol),
                                      atol=float(atol), n_sets=n_sets)
             y = sol.y
             info = {"status": sol.status, "nsteps": sol.nsteps, "nfev": sol.nfev}
@@ -611,7 +611,7 @@ class HybridODENN(nn.Module):
             xs, tt, ins = self._prep_inputs(x0, tp, u, dev)
             info, nl = {}, self.nn_residual
             ss = _GaussLikFn.apply(xs, nn_flat, ode_vec, tt, ins["meal"], ins["tVNS"], ins["GD"],
-                                   obs.to(dev, torch.float32).contiguous(), nl.hidden_dim, nl.n_layers, method, float(rtol),
+                                   obs.to(dev, torch.float32).contiguous(), nl.hidden_dim, nl.hip_layers, method, float(rtol),
                                    float(atol), S, info, group, False, self.tape_steps)
             self.last_solve_info = info
             self._warn_failures(info)
@@ -661,7 +661,7 @@ class HybridODENN(nn.Module):
             nn_flat, ode_vec = self._params_on(dev)
             info, nl = {}, self.nn_residual
             ss, pred = _GaussLikFn.apply(xs, nn_flat, ode_vec, tt, ins["meal"], ins["tVNS"], ins["GD"],
-                                         obs.to(dev, torch.float32).contiguous(), nl.hidden_dim, nl.n_layers, hode.METHOD_DP54,
+                                         obs.to(dev, torch.float32).contiguous(), nl.hidden_dim, nl.hip_layers, hode.METHOD_DP54,
                                          1e-6, 1e-8, 1, info, None, True, self.tape_steps)
             self.last_solve_info = info
             self._warn_failures(info)

@@ -11,6 +11,7 @@ import torch
 import torch.nn as nn
 
 _ACTIVATIONS = {"relu": nn.ReLU, "tanh": nn.Tanh, "elu": nn.ELU, "leaky_relu": lambda: nn.LeakyReLU(0.1)}
+_ACT_CODES = {"relu": 0, "tanh": 1, "elu": 2, "leaky_relu": 3}        # include/hode.h HODE_ACT_*
 
 
 class NNResidual(nn.Module):
@@ -45,10 +46,16 @@ class NNResidual(nn.Module):
 
     # ---- what the HIP kernels consume -----------------------------------------------------
     def hip_supported(self) -> bool:
-        """include/hode.h: ReLU, no dropout, input 9, output 6, hidden <= 128, 1..8 hidden layers (register-resident kernels up
-        to 64 x 4, generic streamed-weight kernels beyond)."""
-        return (self.activation_name == "relu" and self.dropout == 0 and self.input_dim == 9
+        """include/hode.h: no dropout, input 9, output 6, hidden <= 128, 1..8 hidden layers (ReLU up to 64 x 4: the
+        register-resident kernels; beyond that, and for tanh / elu / leaky_relu at any shape, the generic streamed-weight
+        kernels)."""
+        return (self.activation_name in _ACT_CODES and self.dropout == 0 and self.input_dim == 9
                 and self.output_dim == 6 and 1 <= self.hidden_dim <= 128 and 1 <= self.n_layers <= 8)
+
+    @property
+    def hip_layers(self) -> int:
+        """The `L` argument of the C ABI: hidden layers in bits 0..7, activation code in bits 8..15 (HODE_LAYERS)."""
+        return self.n_layers | (_ACT_CODES[self.activation_name] << 8)
 
     def flat_parameters(self) -> torch.Tensor:
         """W1,b1,...,Wout,bout concatenated in parameters() order (differentiable cat)."""

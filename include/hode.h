@@ -55,9 +55,19 @@ extern "C" {
  *   H <= 64 and L <= 4   tuned kernels: all weights register-resident, one hidden unit per wavefront lane;
  *   otherwise            generic kernels (two hidden units per lane, weights streamed from L2, gradients by coalesced
  *                        atomics), same results contract, sized for the batches such shapes are trained with.
- * Activation: ReLU, no dropout.  NNResidual also offers tanh / elu / leaky_relu(0.1) and dropout, but HybridODENN
- * (models/hybrid_ode_nn.py:57-58) never passes either, so no caller of this path can select them: the host class raises
- * NotImplementedError for them instead of silently computing something else. */
+ * Activation: ReLU in the tuned kernels; tanh / elu / leaky_relu(0.1) through the generic kernels (HODE_LAYERS below).  Dropout
+ * (also offered by NNResidual, never passed by HybridODENN, models/hybrid_ode_nn.py:57-58) is a training-time random mask with
+ * no meaning inside an ODE right-hand side that is evaluated six times per step: the host class raises NotImplementedError for
+ * it instead of silently computing something else. */
+/* Activation codes.  The `L` argument of every entry point is HODE_LAYERS(hidden layers, activation): layers in bits 0..7, the
+ * code in bits 8..15 -- a plain layer count means ReLU, which is all HybridODENN ever builds.  tanh / elu (alpha 1) /
+ * leaky_relu (0.1) of NNResidual (models/nn_residual.py:50-56) are reached by replacing `model.nn_residual`; they run through
+ * the generic kernels whatever the shape. */
+#define HODE_ACT_RELU 0
+#define HODE_ACT_TANH 1
+#define HODE_ACT_ELU 2
+#define HODE_ACT_LEAKY_RELU 3
+#define HODE_LAYERS(L, act) (((L) & 0xff) | ((act) << 8))
 #define HODE_MAX_HIDDEN 128
 #define HODE_MAX_LAYERS 8
 #define HODE_TUNED_HIDDEN 64 /* envelope of the register-resident kernels */

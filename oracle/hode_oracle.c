@@ -27,12 +27,16 @@
 #define SFX(x) x##_f32
 #define RPOW(a, b) powf((a), (b))
 #define RLOG(a) logf((a))
+#define RTANH(a) tanhf((a))
+#define REXPM1(a) expm1f((a))
 #include "hode_oracle_impl.h"
 #undef REAL
 #undef ACC
 #undef SFX
 #undef RPOW
 #undef RLOG
+#undef RTANH
+#undef REXPM1
 
 /* ------------------------------------------------------------------ fp64 instantiation */
 #define REAL double
@@ -40,12 +44,16 @@
 #define SFX(x) x##_f64
 #define RPOW(a, b) pow((a), (b))
 #define RLOG(a) log((a))
+#define RTANH(a) tanh((a))
+#define REXPM1(a) expm1((a))
 #include "hode_oracle_impl.h"
 #undef REAL
 #undef ACC
 #undef SFX
 #undef RPOW
 #undef RLOG
+#undef RTANH
+#undef REXPM1
 
 int hode_oracle_tape_entry_size_f32(void) { return (int)sizeof(tape_t_f32); }
 int hode_oracle_tape_entry_size_f64(void) { return (int)sizeof(tape_t_f64); }

@@ -6,7 +6,8 @@
  *
  * What is restated (citations are into /root/reference unless prefixed scipy/):
  *   rhs            models/ode_core.py:104-161 (6 mechanistic terms)
- *                  models/nn_residual.py:114-151 (input row [t,x(6),glp1,tvns] -> MLP, ReLU)
+ *                  models/nn_residual.py:114-151 (input row [t,x(6),glp1,tvns] -> MLP); activation :50-56:
+ *                  relu (default; the only one HybridODENN ever builds), tanh, elu (alpha 1), leaky_relu (0.1)
  *                  models/hybrid_ode_nn.py:108-134 (sum; glp1 := x[3]; tvns from inputs)
  *   input lerp     models/hybrid_ode_nn.py:210-231 (piecewise linear on the grid; dim()==1 -> constant)
  *   DP5(4) step    scipy/integrate/_ivp/rk.py:14-72 (rk_step), :111-176 (_step_impl controller),
@@ -20,8 +21,14 @@
 /* flat nn_p = PyTorch parameters() order (models/nn_residual.py:59-78):
  *   W1[H,9] b1[H] (W[H,H] b[H]) x (L-1)  Wout[6,H] bout[6]                                   */
 
+/* Activation codes (include/hode.h HODE_ACT_*); the `L` argument of every entry point carries one in bits 8..15. */
+#ifndef HODE_ORACLE_ACT_DEFINED
+#define HODE_ORACLE_ACT_DEFINED
+enum { ORACLE_ACT_RELU = 0, ORACLE_ACT_TANH = 1, ORACLE_ACT_ELU = 2, ORACLE_ACT_LEAKY = 3 };
+#endif
+
 typedef struct {
-    int H, L;
+    int H, L, act;
     const REAL *W[HODE_MAXL + 1];
     const REAL *b[HODE_MAXL + 1];
     int in_dim[HODE_MAXL + 1], out_dim[HODE_MAXL + 1];
@@ -30,8 +37,10 @@ typedef struct {
 
 static int SFX(mlp_bind)(SFX(mlp_t) *m, const REAL *p, int H, int L)
 {
-    if (L < 1 || L > HODE_MAXL || H < 1 || H > HODE_MAXH) return -1;
-    m->H = H; m->L = L;
+    const int act = (L >> 8) & 0xff;
+    L &= 0xff;
+    if (L < 1 || L > HODE_MAXL || H < 1 || H > HODE_MAXH || act > ORACLE_ACT_LEAKY) return -1;
+    m->H = H; m->L = L; m->act = act;
     int off = 0;
     for (int l = 0; l <= L; ++l) {
         int in = (l == 0) ? 9 : H, out = (l == L) ? 6 : H;
@@ -40,6 +49,27 @@ static int SFX(mlp_bind)(SFX(mlp_t) *m, const REAL *p, int H, int L)
         m->b_off[l] = off; m->b[l] = p + off; off += out;
     }
     return off;
+}
+
+/* activation and its derivative from the POST-activation value h (torch: nn.ReLU / Tanh / ELU(alpha 1) / LeakyReLU(0.1);
+ * h > 0 iff the pre-activation is > 0 for all four; ELU'(x <= 0) = exp(x) = h + 1) */
+static REAL SFX(act_f)(REAL s, int act)
+{
+    switch (act) {
+    case ORACLE_ACT_TANH: return RTANH(s);
+    case ORACLE_ACT_ELU: return s > 0 ? s : REXPM1(s);
+    case ORACLE_ACT_LEAKY: return s > 0 ? s : (REAL)0.1 * s;
+    default: return s > 0 ? s : (REAL)0;
+    }
+}
+static REAL SFX(act_d)(REAL h, int act)
+{
+    switch (act) {
+    case ORACLE_ACT_TANH: return (REAL)1 - h * h;
+    case ORACLE_ACT_ELU: return h > 0 ? (REAL)1 : h + (REAL)1;
+    case ORACLE_ACT_LEAKY: return h > 0 ? (REAL)1 : (REAL)0.1;
+    default: return h > 0 ? (REAL)1 : (REAL)0;
+    }
 }
 
 /* ---- RHS --------------------------------------------------------------------------------- */
@@ -87,7 +117,7 @@ static void SFX(rhs_one)(const SFX(mlp_t) *m, const REAL *ode, REAL t, const REA
         for (int j = 0; j < nout; ++j) {
             REAL s = b[j];
             for (int k = 0; k < nin; ++k) s += W[j * nin + k] * act[l][k];
-            dst[j] = (l == m->L) ? s : (s > 0 ? s : (REAL)0);
+            dst[j] = (l == m->L) ? s : SFX(act_f)(s, m->act);
         }
     }
     f[0] = dG + out6[0];
@@ -163,7 +193,7 @@ static void SFX(rhs_vjp_one)(const SFX(mlp_t) *m, const REAL *ode, REAL t, const
             for (int k = 0; k < nin; ++k) prev[k] += W[j * nin + k] * d;
         }
         if (l > 0)
-            for (int k = 0; k < nin; ++k) delta[k] = (act[l][k] > 0) ? prev[k] : (REAL)0;
+            for (int k = 0; k < nin; ++k) delta[k] = prev[k] * SFX(act_d)(act[l][k], m->act);
     }
     /* d/dx through input row: x[i] -> in[1+i], x[3] also -> in[7] */
     for (int i = 0; i < 6; ++i) o[i] += prev[1 + i];

@@ -66,7 +66,16 @@ def _mode(a, B, T):
     return 1
 
 
+ACT_RELU, ACT_TANH, ACT_ELU, ACT_LEAKY_RELU = 0, 1, 2, 3
+
+
+def layers(L, act=ACT_RELU):
+    """The `L` argument of every entry point: hidden layers in bits 0..7, activation code in bits 8..15 (include/hode.h)."""
+    return (L & 0xff) | (act << 8)
+
+
 def n_params(H, L):
+    L &= 0xff
     return 9 * H + H + (L - 1) * (H * H + H) + 6 * H + 6
 
 

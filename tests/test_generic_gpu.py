@@ -202,3 +202,75 @@ def test_class_surface_with_the_ablation_network():
     opt.zero_grad()
     m.loss(batch, lambda1=1.0, lambda2=0.1).backward()
     assert float(m.nn_residual.network[0].weight.grad.abs().max()) > 0
+
+
+# ------------------------------------------------------------------------------------------------ activations other than ReLU
+ACTS = [("tanh", 1), ("elu", 2), ("leaky_relu", 3)]
+
+
+@pytest.mark.parametrize("name,code", ACTS)
+def test_activations_rhs_solve_adjoint_vs_reference_and_oracle(hode, golden_dir, name, code):
+    """NNResidual's other activations (reference models/nn_residual.py:50-56): K1 / K5 against values captured from the reference
+    itself (G-act: forward fp32 / fp64, autograd VJP), K2 against its converged trajectories, K4 against the oracle's adjoint
+    (which those captures pin, tests/test_oracle_golden.py).  Any shape with a non-ReLU code takes the generic kernels."""
+    g = np.load(os.path.join(golden_dir, f"g_act_{name}.npz"))
+    H, L = 16, hode.capi.layers(3, code)
+    assert hode.capi.layers(3, code) == 3 + 256 * code and hode.n_params(16, L) == g["nn_flat"].size
+    for dt, tol in ((torch.float64, 1e-11), (torch.float32, 2e-5)):
+        out = hode.rhs_fwd(dev(g["x"], dt), dev(g["t"], dt), dev(g["meal"], dt), dev(g["tvns"], dt), None, dev(g["ode"], dt), dev(g["nn_flat"], dt), H, L)
+        assert rel(out.cpu().numpy(), g["rhs_f64"]) < tol, (name, dt)
+    d64 = torch.float64
+    gx, _, gnn, _ = hode.rhs_bwd(dev(g["x"], d64), dev(g["t"], d64), dev(g["meal"], d64), dev(g["tvns"], d64), None, dev(g["ode"], d64),
+                                 dev(g["nn_flat"], d64), H, L, dev(g["vjp_w"], d64), want_gnn=True)
+    assert rel(gx.cpu().numpy(), g["vjp_gx_f64"]) < 1e-9 and relnorm(gnn.cpu().numpy(), g["vjp_gnn_f64"]) < 1e-10
+    # trajectories: fp64 at tight tolerances and fp32 at the defaults vs the reference's rk45 at 1e-10 (its RHS is fp32: 2e-5)
+    x0, t, meal, tv = g["traj_x0"], g["traj_t"], g["traj_meal"], g["traj_tvns"]
+    s64 = hode.solve_fwd(dev(x0, d64), dev(t, d64), dev(meal, d64), dev(tv, d64), None, dev(g["ode"], d64), dev(g["nn_flat"], d64), H, L,
+                         rtol=1e-10, atol=1e-12, want_tape=True)
+    assert int(s64.status.max()) == 0 and rel(s64.y.cpu().numpy(), g["traj_y_rk45_tight"].astype(np.float64)) < 2e-5
+    d32 = torch.float32
+    s32 = hode.solve_fwd(dev(x0, d32), dev(t, d32), dev(meal, d32), dev(tv, d32), None, dev(g["ode"], d32), dev(g["nn_flat"], d32), H, L, want_tape=True)
+    assert int(s32.status.max()) == 0 and rel(s32.y.cpu().numpy(), g["traj_y_rk45_tight"].astype(np.float64)) < 1e-4
+    # adjoint vs oracle (same activation code convention: oracle.layers)
+    ref = O.solve(x0, t, meal, tv, None, g["ode"], g["nn_flat"], H, O.layers(3, code), rtol=1e-10, atol=1e-12, dtype=np.float64, want_tape=True)
+    c = np.random.default_rng(5).standard_normal(ref.y.shape)
+    rx, rnn, rode = O.solve_bwd(ref, c)
+    gx0, gnn, gode = hode.solve_bwd(s64, dev(c, d64), want_gode=True)
+    assert relnorm(gx0.cpu().numpy(), rx) < 1e-7 and relnorm(gnn.cpu().numpy(), rnn) < 1e-7 and relnorm(gode.cpu().numpy(), rode) < 1e-6
+    gx0, gnn, _ = hode.solve_bwd(s32, dev(c, d32))
+    assert relnorm(gx0.cpu().numpy(), rx) < 1e-4 and relnorm(gnn.cpu().numpy(), rnn) < 1e-4
+    # a code the library does not know is refused, not guessed
+    with pytest.raises(hode.HodeError, match="EUNSUPPORTED"):
+        hode.rhs_fwd(dev(g["x"], d32), dev(g["t"], d32), None, None, None, dev(g["ode"], d32), dev(g["nn_flat"], d32), H, hode.capi.layers(3, 4))
+
+
+def test_model_with_a_tanh_residual_trains_through_the_class_surface(golden_dir):
+    """`model.nn_residual = NNResidual(activation='tanh')` -- the only way the reference reaches a non-ReLU network -- runs forward,
+    loss and backward on the device (generic kernels) and agrees with the torch module it replaces on ode_residual."""
+    import models as M
+    g = np.load(os.path.join(golden_dir, "g_act_tanh.npz"))
+    m = M.HybridODENN(nn_hidden=16, nn_layers=3, device="cuda")
+    m.nn_residual = M.NNResidual(9, 16, 6, 3, activation="tanh").cuda()
+    flat, off = torch.tensor(g["nn_flat"]), 0
+    with torch.no_grad():
+        for p in m.nn_residual.parameters():
+            p.copy_(flat[off:off + p.numel()].reshape(p.shape))
+            off += p.numel()
+    assert m.nn_residual.hip_supported() and m.nn_residual.hip_layers == 3 + 256
+    x, t = torch.tensor(g["x"]).cuda(), torch.tensor(g["t"]).cuda()
+    f = m.ode_residual(t, x, {"meal": torch.tensor(g["meal"]).cuda(), "tVNS": torch.tensor(g["tvns"]).cuda()})
+    assert rel(f.detach().cpu().numpy(), g["rhs_f64"]) < 2e-5
+    x0, tt = torch.tensor(g["traj_x0"]).cuda(), torch.tensor(g["traj_t"]).cuda()
+    ext = {"meal": torch.tensor(g["traj_meal"]).cuda(), "tVNS": torch.tensor(g["traj_tvns"]).cuda()}
+    with torch.no_grad():
+        y = m.forward(x0, tt, ext)
+    assert rel(y.cpu().numpy(), g["traj_y_rk45_tight"].astype(np.float64)) < 1e-4
+    batch = {"initial_state": x0, "observations": y + 0.05 * torch.randn_like(y), "time_points": tt, "external_inputs": ext}
+    loss = m.loss(batch, lambda1=0.5, lambda2=0.1)
+    loss.backward()
+    gr = torch.cat([p.grad.reshape(-1) for p in m.nn_residual.parameters()])
+    assert torch.isfinite(loss) and torch.isfinite(gr).all() and float(gr.abs().max()) > 0
+    with pytest.raises(NotImplementedError):
+        bad = M.HybridODENN(nn_hidden=16, nn_layers=3, device="cuda")
+        bad.nn_residual = M.NNResidual(9, 16, 6, 3, dropout=0.1).cuda()
+        bad.forward(x0, tt, ext)

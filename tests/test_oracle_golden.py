@@ -265,3 +265,26 @@ def test_adjoint_rows_that_copy_x0_and_rows_of_a_failed_trajectory(g0):
                 xm[b, i] -= e
                 fd = (run(xp, t, c, max_steps)[0] - run(xm, t, c, max_steps)[0]) / (2 * e)
                 assert abs(fd - gx0[b, i]) <= 2e-6 * max(1.0, abs(fd)), (t, b, i, fd, gx0[b, i])
+
+
+# ---------------------------------------------------------------------------- activations other than ReLU
+@pytest.mark.parametrize("name,code", [("tanh", O.ACT_TANH), ("elu", O.ACT_ELU), ("leaky_relu", O.ACT_LEAKY_RELU)])
+def test_oracle_activations_vs_reference(golden_dir, name, code):
+    """NNResidual's other activations (models/nn_residual.py:50-56; reached by replacing `model.nn_residual`, HybridODENN itself
+    only builds ReLU): the oracle's RHS, its VJP and its converged trajectories against values captured from the reference
+    (tools/capture_golden.py g_act: a 16 x 3 network with biases on both sides of zero)."""
+    g = np.load(os.path.join(golden_dir, f"g_act_{name}.npz"))
+    L = O.layers(3, code)
+    f64 = O.rhs(g["x"], g["t"], g["meal"], g["tvns"], None, g["ode"], g["nn_flat"], 16, L, dtype=np.float64)
+    assert rel(f64, g["rhs_f64"]) < 1e-12
+    f32 = O.rhs(g["x"], g["t"], g["meal"], g["tvns"], None, g["ode"], g["nn_flat"], 16, L, dtype=np.float32)
+    assert rel(f32, g["rhs_f32"].astype(np.float64)) < 2e-5
+    gx, gnn, _ = O.rhs_vjp(g["x"], g["t"], g["meal"], g["tvns"], None, g["ode"], g["nn_flat"], 16, L, g["vjp_w"], dtype=np.float64)
+    assert rel(gx, g["vjp_gx_f64"]) < 1e-10
+    assert float(np.linalg.norm(gnn - g["vjp_gnn_f64"]) / np.linalg.norm(g["vjp_gnn_f64"])) < 1e-12
+    s = O.solve(g["traj_x0"], g["traj_t"], g["traj_meal"], g["traj_tvns"], None, g["ode"], g["nn_flat"], 16, L, rtol=1e-10, atol=1e-12,
+                dtype=np.float64)
+    assert int(s.status.max()) == 0 and rel(s.y, g["traj_y_rk45_tight"].astype(np.float64)) < 2e-5      # (the reference's RHS is fp32)
+    # the activation really is a different function
+    relu = O.rhs(g["x"], g["t"], g["meal"], g["tvns"], None, g["ode"], g["nn_flat"], 16, 3, dtype=np.float64)
+    assert rel(relu, g["rhs_f64"]) > 1e-3

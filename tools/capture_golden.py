@@ -140,6 +140,42 @@ def g123(m, m2):
     save("g123_rhs.npz", **out)
 
 
+# ----------------------------------------------------------------------------- G-act
+def g_act():
+    """The activations NNResidual offers besides ReLU (models/nn_residual.py:50-56: tanh, elu, leaky_relu(0.1)).  HybridODENN never
+    passes one (hybrid_ode_nn.py:57-58), so they are reached by replacing `model.nn_residual`; what is captured is what such a
+    model computes: NNResidual.forward, ode_residual (fp32 and .double()), the autograd VJP, and a converged rk45 trajectory."""
+    x, t, meal, tvns, gd = rhs_inputs()
+    for act in ("tanh", "elu", "leaky_relu"):
+        torch.manual_seed(11)
+        m = HybridODENN(nn_hidden=16, nn_layers=3, device=CPU)
+        m.nn_residual = NNResidual(input_dim=9, hidden_dim=16, output_dim=6, n_layers=3, activation=act)
+        with torch.no_grad():
+            m.nn_residual.network[-1].weight.normal_(0, 0.05)
+            m.nn_residual.network[-1].bias.normal_(0, 0.01)
+            for lin in [l for l in m.nn_residual.network[:-1] if isinstance(l, torch.nn.Linear)]:
+                lin.bias.normal_(0, 0.3)                      # pre-activations on both sides of zero (ELU / leaky slopes, tanh's knee)
+        md = copy.deepcopy(m).double()
+        out = dict(x=x.numpy(), t=t.numpy(), meal=meal.numpy(), tvns=tvns.numpy(), nn_flat=flat_nn(m), ode=ode_vec(m))
+        with torch.no_grad():
+            out["nn_f32"] = m.nn_residual(t, x, x[:, 3], tvns).numpy()
+            out["nn_f64"] = md.nn_residual(t.double(), x.double(), x[:, 3].double(), tvns.double()).numpy()
+            out["rhs_f32"] = m.ode_residual(t, x, {"meal": meal, "tVNS": tvns}).numpy()
+            out["rhs_f64"] = md.ode_residual(t.double(), x.double(), {"meal": meal.double(), "tVNS": tvns.double()}).numpy()
+        gw = torch.Generator().manual_seed(7)
+        w = torch.randn(x.shape[0], 6, generator=gw).double()
+        xr = x.double().clone().requires_grad_(True)
+        md.zero_grad()
+        (md.ode_residual(t.double(), xr, {"meal": meal.double(), "tVNS": tvns.double()}) * w).sum().backward()
+        out["vjp_w"], out["vjp_gx_f64"] = w.numpy(), xr.grad.numpy()
+        out["vjp_gnn_f64"] = torch.cat([p.grad.reshape(-1) for p in md.nn_residual.parameters()]).numpy()
+        x0, tt, ml, tv = cohort(4, 37, 3.0, "pulses", 21)               # 5-min grid over 3 h, unit meals at indices 6 and 30
+        with torch.no_grad():
+            out["traj_x0"], out["traj_t"], out["traj_meal"], out["traj_tvns"] = x0.numpy(), tt.numpy(), ml.numpy(), tv.numpy()
+            out["traj_y_rk45_tight"] = m.forward(x0, tt, {"meal": ml, "tVNS": tv}, solver="rk45", rtol=1e-10, atol=1e-12).numpy()
+        save(f"g_act_{act}.npz", **out)
+
+
 # ----------------------------------------------------------------------------- G4
 def cohort(B, T, t_end, kind, seed):
     g = torch.Generator().manual_seed(seed)
@@ -439,10 +475,14 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "g5t":          # only the tight-tolerance loss fixtures
         print("G5 tight"); g5_tight()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "gact":         # only the non-ReLU activation fixtures
+        print("G-act"); g_act()
+        sys.exit(0)
     print("G0"); m, m2 = g0()
     print("G1-G3"); g123(m, m2)
     print("G5"); g5()
     print("G5 tight"); g5_tight()
+    print("G-act"); g_act()
     print("G6"); g6()
     print("G7"); g7(m)
     print("G4"); g4(m, m2)
