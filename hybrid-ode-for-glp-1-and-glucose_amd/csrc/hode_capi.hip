@@ -120,7 +120,8 @@ int hode_nn_param_count(int H, int L) { return (H < 1 || layers_of(L) < 1) ? HOD
 
 size_t hode_tape_bytes_hl(int B, int max_steps, int elem_size, int H, int L)
 {
-    if (B < 0 || max_steps < 0 || (elem_size != 4 && elem_size != 8) || H < 1 || H > HODE_MAX_HIDDEN || L < 1 || L > HODE_MAX_LAYERS)
+    if (B < 0 || max_steps < 0 || (elem_size != 4 && elem_size != 8) || H < 1 || H > HODE_MAX_HIDDEN || layers_of(L) < 1 ||
+        layers_of(L) > HODE_MAX_LAYERS || act_of(L) > HODE_ACT_LEAKY_RELU || (L >> 16) != 0)
         return 0;
     return tape_total_bytes(B, max_steps, (size_t)elem_size, H, L);
 }
