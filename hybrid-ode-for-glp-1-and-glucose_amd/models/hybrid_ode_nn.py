@@ -71,11 +71,28 @@ class _RhsFn(torch.autograd.Function):
 TAPE_BUDGET_BYTES = 64 << 30
 
 
-def _tape_budget(dev):
-    """min(TAPE_BUDGET_BYTES, 80 % of what the allocator can still hand out on this device) -- no synchronisation."""
+_budget_cache: Dict[Tuple[int, int], int] = {}
+_span_cache: Dict[torch.device, torch.Tensor] = {}
+
+
+def _short_span(dev):
+    """[0, 0.1] on the device (the physics term's finite-difference step, hybrid_ode_nn.py:318) -- made once."""
+    if dev not in _span_cache:
+        _span_cache[dev] = torch.tensor([0.0, 0.1], dtype=torch.float32, device=dev)
+    return _span_cache[dev]
+
+
+def _tape_budget(dev, need: int = 0):
+    """min(TAPE_BUDGET_BYTES, 80 % of what the allocator can still hand out on this device) -- no synchronisation.
+    Asking the allocator costs ~0.25 ms of host time (memory_stats walks a dictionary), as much as a whole small-batch
+    solve: a caller that passes the bytes it `need`s gets the last answer back while that is at least 4x the need."""
+    key = (torch.device(dev).index or 0, TAPE_BUDGET_BYTES)
+    if need > 0 and 4 * need <= _budget_cache.get(key, 0):
+        return _budget_cache[key]
     free, _ = torch.cuda.mem_get_info(dev)
     reusable = torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)     # cached blocks torch can re-use
-    return max(1, min(TAPE_BUDGET_BYTES, int(0.8 * (free + reusable))))
+    _budget_cache[key] = max(1, min(TAPE_BUDGET_BYTES, int(0.8 * (free + reusable))))
+    return _budget_cache[key]
 
 
 # Accepted-step budget of a solve that records a tape: every step costs 6*(L*256 + 32) + 36 B of tape, so the default is
@@ -105,8 +122,9 @@ class _Taped:
     re-integrated chunk by chunk in backward(), one tape buffer re-used -- the retries are bounded by the same budget as
     everything else (4 096 retried trajectories at 12.6 MB each would otherwise ask for 51 GB on top of the tape)."""
 
-    def __init__(self, sol, extras):
+    def __init__(self, sol, extras, worst=None):
         self.sol, self.extras = sol, extras
+        self.worst = worst                   # max status of the main launch when the host already knows it (0: all fine)
         self.y, self.tape = sol.y, sol.tape
         self.status, self.nsteps, self.nfev = sol.status, sol.nsteps, sol.nfev
         if extras:
@@ -159,8 +177,10 @@ def _solve_taped(x0, t, meal, tvns, gd, ode_vec, nn_flat, H, L, method, rtol, at
                          want_tape=tape is None, tape=tape, max_steps=steps)
     extras = []
     big = _eval_steps(t.shape[-1], method)
+    worst = None
     if big > steps:
-        bad = torch.nonzero(sol.status == 1).flatten()
+        worst = int(sol.status.max())        # the one host synchronisation: 0 in the common case, nothing else to look at
+        bad = torch.nonzero(sol.status == 1).flatten() if worst else sol.status[:0]
         if bad.numel():
             per_set, P = x0.shape[0] // n_sets, nn_flat.numel() // n_sets
             cut = lambda v, i: None if v is None else v[i].contiguous()          # noqa: E731
@@ -184,7 +204,7 @@ def _solve_taped(x0, t, meal, tvns, gd, ode_vec, nn_flat, H, L, method, rtol, at
                     extras.append((idx, set_id, s2, None))
                 else:
                     extras.append((idx, set_id, s2, (solve, max(1, _tape_budget(x0.device) // (2 * per_traj)))))
-    return _Taped(sol, extras)
+    return _Taped(sol, extras, None if extras else worst)
 
 
 class _SolveFn(torch.autograd.Function):
@@ -196,12 +216,14 @@ class _SolveFn(torch.autograd.Function):
         B, T = x0.shape[0], t.shape[-1]
         steps = _tape_steps(T, method, tape_steps)
         per_traj = hode.capi.tape_nbytes(1, steps, x0.element_size(), L, H)
-        budget = _tape_budget(x0.device) if need_tape else 0
+        budget = _tape_budget(x0.device, B * per_traj) if need_tape else 0
         ctx.chunked = need_tape and B * per_traj > budget
         ctx.sol = None
         if need_tape and not ctx.chunked:
             sol = ctx.sol = _solve_taped(x0, t, meal, tvns, gd, ode_vec, nn_flat, H, L, method, rtol, atol, n_sets, steps)
             info["n_budget_retries"] = sol.n_retried
+            if sol.worst is not None:
+                info["worst_status"] = sol.worst
         else:
             # above the tape budget: no tape now, the backward re-integrates chunk by chunk (same trajectories: a
             # trajectory's result does not depend on its step budget unless it runs out, and then it is retried)
@@ -289,12 +311,13 @@ class _GaussLikFn(torch.autograd.Function):
         B, T = x0.shape[0], t.shape[-1]
         P = nn_flat.numel() // S
         steps = _tape_steps(T, method, tape_steps)
-        cap = max(1, _tape_budget(x0.device) // hode.capi.tape_nbytes(1, steps, x0.element_size(), L, H)) if grads else S * B
+        per_traj = hode.capi.tape_nbytes(1, steps, x0.element_size(), L, H)
+        cap = max(1, _tape_budget(x0.device, S * B * per_traj) // per_traj) if grads else S * B
         ss = torch.zeros(1, dtype=torch.float64, device=x0.device)
         gx0 = torch.zeros_like(x0) if need[0] else None
         gnn = torch.zeros_like(nn_flat) if need[1] else None
         gode = torch.zeros_like(ode_vec) if need[2] else None
-        tape, stat, nst, nfe, ys, retried = None, [], [], [], [], 0
+        tape, stat, nst, nfe, ys, retried, worst = None, [], [], [], [], 0, 0
         for s0, s1, lo, hi in _pieces(S, B, cap):
             m = s1 - s0
             rep = lambda v: None if v is None else (v[lo:hi].repeat(m, *([1] * (v.dim() - 1))) if m > 1 else v[lo:hi])  # noqa: E731
@@ -303,6 +326,7 @@ class _GaussLikFn(torch.autograd.Function):
                                    nn_flat[P * s0:P * s1], H, L, method, rtol, atol, m, steps, tape=tape)
                 tape = sol.tape
                 retried += sol.n_retried
+                worst = None if (worst is None or sol.worst is None) else max(worst, sol.worst)
             else:
                 sol = hode.solve_fwd(rep(x0), t if t.dim() == 1 else rep(t), rep(meal), rep(tvns), rep(gd), ode_vec[17 * s0:17 * s1],
                                      nn_flat[P * s0:P * s1], H, L, method=method, rtol=rtol, atol=atol, n_sets=m)
@@ -318,8 +342,11 @@ class _GaussLikFn(torch.autograd.Function):
             stat.append(sol.status), nst.append(sol.nsteps), nfe.append(sol.nfev)
             if want_y:
                 ys.append(sol.y)
-        info["status"], info["nsteps"], info["nfev"] = torch.cat(stat), torch.cat(nst), torch.cat(nfe)
+        one = len(stat) == 1
+        info["status"], info["nsteps"], info["nfev"] = (stat[0], nst[0], nfe[0]) if one else (torch.cat(stat), torch.cat(nst), torch.cat(nfe))
         info["n_budget_retries"] = retried
+        if grads and worst is not None:
+            info["worst_status"] = worst          # the host has already looked (one synchronisation per piece): 0 = nothing failed
         if group is not None:
             # patients sharded over the ranks, the SAME S draws everywhere: one all-reduce(sum) of
             # [per-set MLP grads | per-set ODE grads | sum of squares] makes value and gradient global on every rank
@@ -425,8 +452,9 @@ class HybridODENN(nn.Module):
 
     # ------------------------------------------------------------------ RHS
     def ode_residual(self, t: torch.Tensor, state: torch.Tensor,
-                     external_inputs: Optional[Dict[str, torch.Tensor]] = None) -> torch.Tensor:
-        """f(t, x, u) = ODECore + NNResidual(t, x, x[...,3], tVNS) on the device (K1; K5 for grads)."""
+                     external_inputs: Optional[Dict[str, torch.Tensor]] = None, _flat=None) -> torch.Tensor:
+        """f(t, x, u) = ODECore + NNResidual(t, x, x[...,3], tVNS) on the device (K1; K5 for grads).
+        `_flat`: (nn_flat, ode_vec) the caller has already gathered (loss() builds them once per step)."""
         self._check_supported()
         dev = _compute_device()
         single = state.dim() == 1
@@ -435,7 +463,7 @@ class HybridODENN(nn.Module):
         tt = torch.as_tensor(t).to(dev, torch.float32)
         tt = tt.reshape(1).expand(n) if tt.numel() == 1 else tt.reshape(n)
         meal, tvns, gd = (self._input(external_inputs, k, dev, n) for k in ("meal", "tVNS", "GD"))
-        nn_flat, ode_vec = self._params_on(dev)
+        nn_flat, ode_vec = self._params_on(dev) if _flat is None else _flat
         nl = self.nn_residual
         out = _RhsFn.apply(x.contiguous(), tt.contiguous(), nn_flat, ode_vec, meal, tvns, gd, nl.hidden_dim, nl.hip_layers)
         out = out.to(state.device)
@@ -497,7 +525,7 @@ class HybridODENN(nn.Module):
 
     def _warn_failures(self, info):
         """Never raise on an integration failure: log and keep the zero rows (hybrid_ode_nn.py:243-256)."""
-        if logger.isEnabledFor(logging.WARNING) and "status" in info:
+        if logger.isEnabledFor(logging.WARNING) and "status" in info and info.get("worst_status", 1) != 0:
             bad = torch.nonzero(info["status"]).flatten()
             if bad.numel():
                 msgs = {1: "step budget exhausted", 2: "Required step size is less than spacing between numbers.",
@@ -652,13 +680,22 @@ class HybridODENN(nn.Module):
         tp = batch["time_points"]
         u = batch.get("external_inputs", None)
         dev = _compute_device()
+        self._check_supported()
+        nn_flat, ode_vec = self._params_on(dev)        # gathered ONCE per step: the solve, the physics solve and f() share them
+        idx = None
+        if use_physics_loss and lambda1 > 0:
+            # the physics indices are drawn and shipped to the device BEFORE the solve is queued: a host-to-device copy
+            # from pageable memory waits for the stream, and here the stream is still empty.  Same draw as the reference,
+            # whose randperm follows its solve: nothing on this path consumes torch's host generator in between
+            n = min(20, len(tp))
+            idx = torch.randperm(len(tp))[:n]                         # global RNG, same draw as the reference
+            idx = idx[idx < tp.shape[-1]]                              # (the reference raises IndexError here)
+            idx_d = idx.to(dev)
 
         if self.fused_likelihood and self.adjoint and torch.is_grad_enabled():
             # solve + MSE + adjoint piece by piece in one pass (_GaussLikFn): no tape is held until backward() and a
             # cohort whose tape exceeds the budget needs no second forward.  Defaults like reference :291.
-            self._check_supported()
             xs, tt, ins = self._prep_inputs(x0, tp, u, dev)
-            nn_flat, ode_vec = self._params_on(dev)
             info, nl = {}, self.nn_residual
             ss, pred = _GaussLikFn.apply(xs, nn_flat, ode_vec, tt, ins["meal"], ins["tVNS"], ins["GD"],
                                          obs.to(dev, torch.float32).contiguous(), nl.hidden_dim, nl.hip_layers, hode.METHOD_DP54,
@@ -667,19 +704,15 @@ class HybridODENN(nn.Module):
             self._warn_failures(info)
             data_loss = (ss / obs.numel()).float()
         else:
-            pred = self._solve(x0, tp, u, "dopri5", 1e-6, 1e-8)      # defaults, like reference :291
+            pred = self._solve(x0, tp, u, "dopri5", 1e-6, 1e-8,      # defaults, like reference :291
+                               nn_flat=nn_flat, ode_vec=ode_vec)
             self._warn_failures(self.last_solve_info)
             data_loss = torch.nn.functional.mse_loss(pred, obs.to(dev, torch.float32))
 
         physics_loss = torch.zeros((), device=dev)
-        if use_physics_loss and lambda1 > 0:
-            T = pred.shape[1]
-            n = min(20, len(tp))
-            idx = torch.randperm(len(tp))[:n]                         # global RNG, same draw as the reference
-            idx = idx[idx < T]                                         # (the reference raises IndexError here)
+        if idx is not None:
             if idx.numel() > 0:
                 B, m = pred.shape[0], idx.numel()
-                idx_d = idx.to(dev)
                 state = pred.detach()[:, idx_d, :].transpose(0, 1).reshape(m * B, 6).contiguous()   # [m*B, 6]
                 tpd = tp.to(dev, torch.float32)
                 t_true = (tpd[:, idx_d].transpose(0, 1) if tpd.dim() == 2 else tpd[idx_d].unsqueeze(1).expand(m, B)).reshape(m * B)
@@ -688,9 +721,10 @@ class HybridODENN(nn.Module):
                     v = torch.as_tensor(v).to(dev, torch.float32)
                     ext[key] = (v[:, idx_d].transpose(0, 1) if v.dim() == 2 else v.reshape(1, -1).expand(m, B)).reshape(m * B).contiguous()
                 with torch.no_grad():                                  # FD target carries no gradient (reference: detached solve)
-                    nxt = self._solve(state, torch.tensor([0.0, 0.1]), ext, "dopri5", 1e-6, 1e-8, differentiable=False)[:, 1, :]
+                    nxt = self._solve(state, _short_span(dev), ext, "dopri5", 1e-6, 1e-8, differentiable=False,
+                                      nn_flat=nn_flat, ode_vec=ode_vec)[:, 1, :]
                     fd = (nxt - state) / 0.1
-                f = self.ode_residual(t_true, state.requires_grad_(True), ext)
+                f = self.ode_residual(t_true, state.requires_grad_(True), ext, _flat=(nn_flat, ode_vec))
                 # mean over indices of per-index MSE == MSE over the stacked [m*B, 6] block
                 physics_loss = torch.nn.functional.mse_loss(fd, f) * (m / n)
 

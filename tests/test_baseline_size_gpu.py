@@ -396,13 +396,13 @@ def test_cfg5_elbo_4x64_16_draws_value_and_gradient_vs_per_draw_oracle(monkeypat
         assert abs(a - b) < 1e-4 * abs(b) + 5e-4 * float(np.abs(gmu_o[name]).max()), (name, a, b)
     # ---- the chunked route: the tape budget admits two draws (16 trajectories) per piece
     per_traj = __import__("hode").capi.tape_nbytes(1, MH._tape_steps(Tn, 0, None), 4, L, H)
-    monkeypatch.setattr(MH, "_tape_budget", lambda dev_: 2 * B * per_traj + 1)
+    monkeypatch.setattr(MH, "_tape_budget", lambda dev_, *a: 2 * B * per_traj + 1)
     assert len(MH._pieces(S, B, 2 * B)) == 8
     e2, ll2, kl2, gmu2, gls2 = run()
     assert abs(e2 - e) < 1e-9 * abs(e) and kl2 == kl
     assert relnorm(flat(gmu2, names_nn), flat(gmu, names_nn)) < 1e-5 and relnorm(flat(gls2, names_nn), flat(gls, names_nn)) < 1e-5
     # ... and slices of one draw (budget below one draw's 8 trajectories)
-    monkeypatch.setattr(MH, "_tape_budget", lambda dev_: 3 * per_traj + 1)
+    monkeypatch.setattr(MH, "_tape_budget", lambda dev_, *a: 3 * per_traj + 1)
     e3, _, _, gmu3, _ = run()
     assert abs(e3 - e) < 1e-9 * abs(e) and relnorm(flat(gmu3, names_nn), flat(gmu, names_nn)) < 1e-5
 

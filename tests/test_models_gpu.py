@@ -323,7 +323,7 @@ def test_retried_trajectories_whose_tapes_exceed_the_budget_are_reintegrated_pie
         m.tape_steps = 14
         if squeeze:
             big = hode.capi.tape_nbytes(1, MH._eval_steps(11, hode.METHOD_DP54), 4, 4, 64)
-            monkeypatch.setattr(MH, "_tape_budget", lambda dev_: int(2.5 * big))
+            monkeypatch.setattr(MH, "_tape_budget", lambda dev_, *a: int(2.5 * big))
         y = m.forward(x0, t, u, rtol=1e-9, atol=1e-11)
         assert m.solve_failures() == 0 and m.last_solve_info["n_budget_retries"] == 5
         c = torch.randn(y.shape, device="cuda", generator=torch.Generator("cuda").manual_seed(8))
