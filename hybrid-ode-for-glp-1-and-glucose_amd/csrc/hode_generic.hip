@@ -166,10 +166,52 @@ struct TeamAcc {
     // four separate arrays, not one [4][8][2]: hipcc folds a switch over identical case bodies into a dynamically indexed access,
     // and a dynamically indexed register array lives in scratch
     float m0[8][2], m1[8][2], m2[8][2], m3[8][2];
+    // The gradients of everything that is NOT a hidden matrix -- first layer, output layer, every bias: 2 566 values for 5 x 128 --
+    // were the other half of the adjoint's time as atomics (every team adds to the same 10 KB at every stage: 92 ms -> 46 ms for
+    // 1 024 x 61 without them, 8.7 -> 6.7 ms for 32 x 61).  All waves of a team hold the same cotangents, so the pieces are dealt
+    // out over the waves, twelve registers each (units j = lane and lane + 64 in [.][0] and [.][1]):
+    //   wave 0: the six rows of the output matrix             wave 1: columns 0..4 of the first matrix, and the output bias
+    //   wave 2: columns 5..8 of the first matrix, its bias     wave 3 + l: the bias of hidden matrix l
+    float e[6][2];
+    static constexpr int kEdgeOut = 0, kEdgeIn0 = 1, kEdgeIn1 = 2, kEdgeBias = 3;
     __device__ __forceinline__ void zero()
     {
 #pragma unroll
         for (int u = 0; u < 8; ++u) m0[u][0] = m0[u][1] = m1[u][0] = m1[u][1] = m2[u][0] = m2[u][1] = m3[u][0] = m3[u][1] = 0.f;
+#pragma unroll
+        for (int u = 0; u < 6; ++u) e[u][0] = e[u][1] = 0.f;
+    }
+    // one atomic per entry and WORKGROUP for this wave's edge piece
+    __device__ __forceinline__ void flush_edge(const StreamNet<float> &n, float *__restrict__ g, int part, int lane)
+    {
+        const int H = n.H;
+        const bool vA = lane < H, vB = lane + 64 < H;
+        if (part == kEdgeOut) {
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+                if (vA) atomic_add(g + n.out_off() + q * H + lane, e[q][0]);
+                if (vB) atomic_add(g + n.out_off() + q * H + lane + 64, e[q][1]);
+            }
+        } else if (part == kEdgeIn0) {
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                if (vA) atomic_add(g + lane * 9 + i, e[i][0]);
+                if (vB) atomic_add(g + (lane + 64) * 9 + i, e[i][1]);
+            }
+            if (lane < 6) atomic_add(g + n.out_off() + 6 * H + lane, e[5][0]);
+        } else if (part == kEdgeIn1) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (vA) atomic_add(g + lane * 9 + 5 + i, e[i][0]);
+                if (vB) atomic_add(g + (lane + 64) * 9 + 5 + i, e[i][1]);
+            }
+            if (vA) atomic_add(g + 9 * H + lane, e[4][0]);
+            if (vB) atomic_add(g + 9 * H + lane + 64, e[4][1]);
+        } else if (part - kEdgeBias < n.L - 1) {
+            float *__restrict__ gb = g + n.hid_off(part - kEdgeBias) + (size_t)H * H;
+            if (vA) atomic_add(gb + lane, e[0][0]);
+            if (vB) atomic_add(gb + lane + 64, e[0][1]);
+        }
     }
     // matrix l (wave-uniform, 0 .. kGenAccMats - 1) += p
     __device__ __forceinline__ void add(int l, const float (&pa)[8], const float (&pb)[8])
@@ -200,9 +242,10 @@ struct TeamAcc {
         }
     }
     // one atomic per entry and WORKGROUP (after all its trajectories of a parameter set)
-    __device__ __forceinline__ void flush(const StreamNet<float> &n, float *__restrict__ g, int j0, int lane)
+    __device__ __forceinline__ void flush(const StreamNet<float> &n, float *__restrict__ g, int j0, int lane, int part)
     {
         if (g == nullptr) return;
+        flush_edge(n, g, part, lane);
         const int nm = n.L - 1;
         if (nm > 0) flush_one(m0, g + n.hid_off(0), n.H, j0, lane);
         if (nm > 1) flush_one(m1, g + n.hid_off(1), n.H, j0, lane);
@@ -227,7 +270,9 @@ __device__ __forceinline__ R rhs_vjp_stream(const StreamNet<R> &n, R *__restrict
     // this wave's rows of every hidden matrix (multiples of 8: the chunked loads below), and who adds the non-matrix gradients
     const int rows_per = (((H + NW - 1) / NW) + 7) & ~7;
     const int j0 = (part * rows_per < H) ? part * rows_per : H, j1 = (j0 + rows_per < H) ? j0 + rows_per : H;
-    R *__restrict__ gedge = (part == 0) ? g : nullptr;                   // biases, first and last layer: the team's first wave
+    constexpr bool kAcc = std::is_same<ACC, TeamAcc>::value;
+    // biases, first and last layer: atomics of the team's first wave -- or, with register accumulators, dealt out over the waves
+    R *__restrict__ gedge = (part == 0 && !kAcc) ? g : nullptr;
     // output layer
     R hA = rec[(2 * (L - 1)) * kWave + lane], hB = rec[(2 * (L - 1) + 1) * kWave + lane];
     R dA = R(0), dB = R(0);
@@ -241,6 +286,16 @@ __device__ __forceinline__ R rhs_vjp_stream(const StreamNet<R> &n, R *__restrict
         }
     }
     if (gedge && lane < 6) atomic_add(gedge + n.out_off() + 6 * H + lane, kb);
+    if constexpr (kAcc) {
+        if (g) {
+            if (part == TeamAcc::kEdgeOut) {
+#pragma unroll
+                for (int q = 0; q < 6; ++q) { acc.e[q][0] = rfma(lq[q], hA, acc.e[q][0]); acc.e[q][1] = rfma(lq[q], hB, acc.e[q][1]); }
+            } else if (part == TeamAcc::kEdgeIn0) {
+                acc.e[5][0] += kb;                             // output bias: lanes 0..5 carry the six components
+            }
+        }
+    }
     dA = vA ? act_bwd(dA, hA, n.act) : R(0);
     dB = vB ? act_bwd(dB, hB, n.act) : R(0);
     // hidden matrices, last to first: matrix l maps h_l (rows 2l, 2l+1 of the record) to h_{l+1}
@@ -251,6 +306,9 @@ __device__ __forceinline__ R rhs_vjp_stream(const StreamNet<R> &n, R *__restrict
         if (gedge) {
             if (vA) atomic_add(gW + (size_t)H * H + jA, dA);
             if (vB) atomic_add(gW + (size_t)H * H + jB, dB);
+        }
+        if constexpr (kAcc) {
+            if (g && part == TeamAcc::kEdgeBias + l) { acc.e[0][0] += dA; acc.e[0][1] += dB; }    // d is 0 on masked lanes
         }
         // Two passes over the rows.  vmcnt retires in issue order, so a load issued behind an atomic waits for that atomic's
         // round trip to memory: with loads and atomics interleaved row by row every chunk of loads waited ~1 000 cycles for
@@ -320,6 +378,19 @@ __device__ __forceinline__ R rhs_vjp_stream(const StreamNet<R> &n, R *__restrict
         for (int i = 0; i < 9; ++i) {
             if (vA) atomic_add(gedge + jA * 9 + i, dA * in[i]);
             if (vB) atomic_add(gedge + jB * 9 + i, dB * in[i]);
+        }
+    }
+    if constexpr (kAcc) {
+        if (g) {
+            if (part == TeamAcc::kEdgeIn0) {
+#pragma unroll
+                for (int i = 0; i < 5; ++i) { acc.e[i][0] = rfma(dA, in[i], acc.e[i][0]); acc.e[i][1] = rfma(dB, in[i], acc.e[i][1]); }
+            } else if (part == TeamAcc::kEdgeIn1) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { acc.e[i][0] = rfma(dA, in[5 + i], acc.e[i][0]); acc.e[i][1] = rfma(dB, in[5 + i], acc.e[i][1]); }
+                acc.e[4][0] += dA;
+                acc.e[4][1] += dB;
+            }
         }
     }
     R w[9];
@@ -480,7 +551,7 @@ __global__ __launch_bounds__(64 * kGenTeam) void solve_bwd_generic_kernel(const 
         R *__restrict__ g = a.gnn ? a.gnn + (size_t)set * a.P : nullptr;
         if constexpr (ACCREG) {
             if (set != acc_set) {                           // a workgroup's trajectories come set by set: flush when the set changes
-                if (acc_set >= 0) acc.flush(StreamNet<R>{a.nn_p + (size_t)acc_set * a.P, a.H, L, a.act}, a.gnn ? a.gnn + (size_t)acc_set * a.P : nullptr, j0_k, lane);
+                if (acc_set >= 0) acc.flush(StreamNet<R>{a.nn_p + (size_t)acc_set * a.P, a.H, L, a.act}, a.gnn ? a.gnn + (size_t)acc_set * a.P : nullptr, j0_k, lane, part);
                 acc.zero();
                 acc_set = set;
             }
@@ -545,7 +616,7 @@ __global__ __launch_bounds__(64 * kGenTeam) void solve_bwd_generic_kernel(const 
         }
     }
     if constexpr (ACCREG) {
-        if (acc_set >= 0) acc.flush(StreamNet<R>{a.nn_p + (size_t)acc_set * a.P, a.H, L, a.act}, a.gnn ? a.gnn + (size_t)acc_set * a.P : nullptr, j0_k, lane);
+        if (acc_set >= 0) acc.flush(StreamNet<R>{a.nn_p + (size_t)acc_set * a.P, a.H, L, a.act}, a.gnn ? a.gnn + (size_t)acc_set * a.P : nullptr, j0_k, lane, part);
     }
 }
 
@@ -568,9 +639,11 @@ template <typename R, int NW, bool ACCREG> static int launch_bwd_generic_t(hipSt
 template <typename R> int launch_solve_bwd_generic(hipStream_t s, const AdjArgs<R> &a, int L, int method)
 {
     if constexpr (sizeof(R) == 4) {
-        // fp32, at most kGenAccMats hidden matrices: their gradients accumulate in the team's registers (eight rows per wave).
-        // Measured (5 x 128 / 5 x 64, T = 61): B = 32: 8.5 against 9.0 ms / 5.8 against 4.4; B = 256: 23.6 against 31.2 / 22.2
-        // against 24.9; B = 1 024: 91 against 135 / 87 against 99 -- the narrow network at the reference's batch keeps the atomics
+        // fp32, at most kGenAccMats hidden matrices: ALL parameter gradients accumulate in the team's registers (eight rows of every
+        // hidden matrix per wave, the edge pieces dealt out over the waves) and leave once per workgroup.
+        // Measured (5 x 128 / 5 x 64, T = 61, accumulators against atomics): B = 32: 7.3 against 9.0 ms / 5.2 against 4.1;
+        // B = 256: 12.2 against 31.2 / 7.2 against 24.9; B = 1 024: 48.8 against 135 / 28.9 against 99 -- the narrow network at
+        // the reference's batch keeps the atomics
         if (L - 1 <= kGenAccMats && a.gnn != nullptr && (a.H > 64 || a.B > 128))
             return a.H > 64 ? launch_bwd_generic_t<R, 16, true>(s, a, L, method) : launch_bwd_generic_t<R, 8, true>(s, a, L, method);
     }
