@@ -18,6 +18,20 @@ template <typename R> __device__ __forceinline__ R inp_at(const R *__restrict__ 
     return (mode == 1) ? p[b] : p[(size_t)b * T + k];
 }
 
+// The time grid and the input arrays of the FORWARD solve, read through the constant address space: wave-uniform addresses in
+// memory the kernel never writes, so the loads are scalar (s_load_dword, counted by lgkmcnt) instead of vector loads with a uniform
+// address (counted by vmcnt).  hipcc cannot prove the second property itself -- the kernel stores y and the tape through other
+// pointers of the same argument struct -- and a vector load is followed by s_waitcnt vmcnt(0), which retires IN ORDER: once per
+// grid interval the wave sat out the L2 round trip of four loads and, in the taping instantiation, the acknowledgement of the 30
+// record stores of the step before them.
+template <typename R> using CPtr = const R __attribute__((address_space(4))) *;
+template <typename R> __device__ __forceinline__ CPtr<R> as_const_mem(const R *p) { return (CPtr<R>)p; }
+template <typename R> __device__ __forceinline__ R inp_at(CPtr<R> p, int mode, int b, int T, int k)
+{
+    if (mode == 0) return R(0);
+    return (mode == 1) ? p[b] : p[(size_t)b * T + k];
+}
+
 template <typename R> struct Eps;
 template <> struct Eps<float> { static constexpr float v = 1.1920929e-7f; };
 template <> struct Eps<double> { static constexpr double v = 2.220446049250313e-16; };
@@ -39,7 +53,11 @@ template <typename R, int NL, typename WT> struct RhsRegs {
         if (rec != nullptr) {
             ActsToRecord<R> ac{rec + lane};
             const R F = rhs_eval<R, NL, true>(W, o, ts, Ys, meal, tvns, gde, lane, &ac);
-            if (lane < 8) ac.dst[NL * kWave] = Ys;
+            // the stage state: every octet of the replicated layout holds the same six values (slots 6, 7: zeros), so all 64 lanes
+            // store to the 8 reals -- identical bits per address -- instead of masking 56 lanes off (exec save / branch / restore)
+            int l7 = lane & 7;
+            asm volatile("" : "+v"(l7));                    // (recomputed per stage: a hoisted copy costs a VGPR the kernel does not have)
+            rec[NL * kWave + l7] = Ys;
             return F;
         }
         return rhs_eval<R, NL, false>(W, o, ts, Ys, meal, tvns, gde, lane, (MlpActs<R, NL> *)nullptr);
@@ -73,7 +91,8 @@ __device__ __forceinline__ void solve_one(const SolveArgs<R> &a, const int b, co
 {
     const int c8 = lane & 7, grp = lane >> 3;
     const int T = a.T;
-    const R *__restrict__ tg = a.t + (a.t_batched ? (size_t)b * T : 0);
+    const CPtr<R> tg = as_const_mem(a.t + (a.t_batched ? (size_t)b * T : 0));
+    const CPtr<R> meal_ = as_const_mem(a.meal), tvns_ = as_const_mem(a.tvns), gd_ = as_const_mem(a.gd);
     R *__restrict__ yb = a.y + (size_t)b * T * 6;
     R *__restrict__ tape = TAPE ? a.tape + (size_t)b * a.max_steps * 8 : nullptr;
     int *__restrict__ tseg = TAPE ? a.tape_seg + (size_t)b * a.max_steps : nullptr;
@@ -124,9 +143,9 @@ __device__ __forceinline__ void solve_one(const SolveArgs<R> &a, const int b, co
 
     for (; k + 1 < T && st == HODE_ST_OK; ++k) {
         const R t0 = tg[k], t1 = tg[k + 1];
-        const R m0 = inp_at(a.meal, a.meal_mode, b, T, k), m1 = inp_at(a.meal, a.meal_mode, b, T, k + 1);
-        const R v0 = inp_at(a.tvns, a.tvns_mode, b, T, k), v1 = inp_at(a.tvns, a.tvns_mode, b, T, k + 1);
-        const R d0 = inp_at(a.gd, a.gd_mode, b, T, k), d1 = inp_at(a.gd, a.gd_mode, b, T, k + 1);
+        const R m0 = inp_at<R>(meal_, a.meal_mode, b, T, k), m1 = inp_at<R>(meal_, a.meal_mode, b, T, k + 1);
+        const R v0 = inp_at<R>(tvns_, a.tvns_mode, b, T, k), v1 = inp_at<R>(tvns_, a.tvns_mode, b, T, k + 1);
+        const R d0 = inp_at<R>(gd_, a.gd_mode, b, T, k), d1 = inp_at<R>(gd_, a.gd_mode, b, T, k + 1);
         const R len = t1 - t0;
         if (!(len > R(0))) {                  // repeated grid time: copy the state
             y_put(Y);
@@ -136,16 +155,14 @@ __device__ __forceinline__ void solve_one(const SolveArgs<R> &a, const int b, co
         const R dm = first_lane(m1 - m0), dv = first_lane(v1 - v0), dd = first_lane(d1 - d0);
         // piecewise-linear forcing on this interval (models/hybrid_ode_nn.py:217-229)
         // slot >= 0 (TAPE): also record the layer activations and the stage state for the adjoint
-        auto f_at = [&](R ts, R Ys, int slot) -> R {
+        auto f_at = [&](R ts, R Ys, R *__restrict__ rec) -> R {
             const R al = (ts - t0) * inv_len;
             R gde = R(0);
             if constexpr (use_gd) gde = gd_effect(o, rfma(al, dd, d0));
-            R *rec = nullptr;
-            if constexpr (TAPE) {
-                if (slot >= 0 && slot < a.max_steps * 6) rec = stg + (size_t)slot * kSlot;
-            }
-            return rhs(ts, Ys, rfma(al, dm, m0), rfma(al, dv, v0), gde, rec);
+            return rhs(ts, Ys, rfma(al, dm, m0), rfma(al, dv, v0), gde, TAPE ? rec : nullptr);
         };
+        // stage record `slot` of this trajectory (TAPE): the caller guarantees 0 <= slot < 6 max_steps
+        auto rec_at = [&](int slot) -> R * { return TAPE ? stg + (size_t)slot * kSlot : nullptr; };
         // `closes`: the step ends exactly on the grid point t1 (bit 30 of the interval index; the adjoint needs it to know
         // which grid rows a FAILED trajectory still wrote)
         auto tape_put = [&](R tc, R h, bool closes) {
@@ -169,7 +186,7 @@ __device__ __forceinline__ void solve_one(const SolveArgs<R> &a, const int b, co
 #pragma unroll 1
             for (int s = 0; s < 4; ++s) {
                 const R Ys = rfma(hh, group_sum8(rows[s * kWave + lane] * KK), Y);
-                const R F = f_at(rfma((R)tab.c[s], hh, t0), Ys, ns * 6 + s);
+                const R F = f_at(rfma((R)tab.c[s], hh, t0), Ys, rec_at(ns * 6 + s));       // ns < max_steps (checked above)
                 KK = stage_put(KK, F, s);
             }
             const R Yn4 = rfma(hh, group_sum8(rows[7 * kWave + lane] * KK), Y);
@@ -183,14 +200,14 @@ __device__ __forceinline__ void solve_one(const SolveArgs<R> &a, const int b, co
         } else {
             if (!have_f) {
                 // first derivative + Hairer's initial step (scipy/integrate/_ivp/common.py:68-135)
-                const R K1 = f_at(t0, Y, 0);
+                const R K1 = f_at(t0, Y, a.max_steps > 0 ? rec_at(0) : nullptr);
                 const R sc = (c8 < 6) ? (a.atol + rabs(Y) * a.rtol) : R(1);
                 const R q0 = Y / sc, q1 = K1 / sc;
                 const float dn0 = sqrtf((float)first_lane(oct_allsum(q0 * q0)) / 6.0f);
                 const float dn1 = sqrtf((float)first_lane(oct_allsum(q1 * q1)) / 6.0f);
                 float h0 = (dn0 < 1e-5f || dn1 < 1e-5f) ? 1e-6f : 0.01f * dn0 / dn1;
                 h0 = fminf(h0, (float)len);
-                const R f1 = f_at(t0 + (R)h0, rfma((R)h0, K1, Y), -1);
+                const R f1 = f_at(t0 + (R)h0, rfma((R)h0, K1, Y), nullptr);
                 const R q2 = (f1 - K1) / sc;
                 const float dn2 = sqrtf((float)first_lane(oct_allsum(q2 * q2)) / 6.0f) / h0;
                 const float h1 = (dn1 <= 1e-15f && dn2 <= 1e-15f) ? fmaxf(1e-6f, h0 * 1e-3f)
@@ -216,6 +233,10 @@ __device__ __forceinline__ void solve_one(const SolveArgs<R> &a, const int b, co
                     // the coefficient row and node of stage s+1 are fetched from LDS BEFORE the RHS of stage s,
                     // so the LDS latency hides behind the MLP instead of opening every stage
                     R coef = rows[1 * kWave + lane], cs = cvec[1];
+                    // stage s writes record 6 ns + s (s = 6, the FSAL stage, is record 0 of the NEXT step).  ns < max_steps holds
+                    // here, so only the FSAL stage can fall off the tape: one flag per step instead of a range check of the slot
+                    // at every stage (twelve scalar instructions, every one an issue slot of the wave)
+                    const bool fsal_fits = ns + 1 < a.max_steps;
 #pragma unroll 1
                     for (int s = 1; s <= 6; ++s) {        // stages 2..6 and the FSAL stage (row 6 = 5th-order weights)
                         Ys = rfma(h, group_sum8(coef * KK), Y);
@@ -225,7 +246,7 @@ __device__ __forceinline__ void solve_one(const SolveArgs<R> &a, const int b, co
                         coef = rows[(s + 1) * kWave + lane];   // s = 6 fetches row 7 = error weights
                         cs = cvec[(s + 1) & 7];
                         // stage s of this step; the FSAL stage (s == 6) is stage 0 of the NEXT step
-                        F = f_at(ts, Ys, (s < 6) ? ns * 6 + s : (ns + 1) * 6);
+                        F = f_at(ts, Ys, (s < 6 || fsal_fits) ? rec_at(ns * 6 + s) : nullptr);
                         KK = stage_put(KK, F, s);
                     }
                     const R Yn = Ys;                      // 5th-order solution
