@@ -18,20 +18,6 @@ template <typename R> __device__ __forceinline__ R inp_at(const R *__restrict__ 
     return (mode == 1) ? p[b] : p[(size_t)b * T + k];
 }
 
-// The time grid and the input arrays of the FORWARD solve, read through the constant address space: wave-uniform addresses in
-// memory the kernel never writes, so the loads are scalar (s_load_dword, counted by lgkmcnt) instead of vector loads with a uniform
-// address (counted by vmcnt).  hipcc cannot prove the second property itself -- the kernel stores y and the tape through other
-// pointers of the same argument struct -- and a vector load is followed by s_waitcnt vmcnt(0), which retires IN ORDER: once per
-// grid interval the wave sat out the L2 round trip of four loads and, in the taping instantiation, the acknowledgement of the 30
-// record stores of the step before them.
-template <typename R> using CPtr = const R __attribute__((address_space(4))) *;
-template <typename R> __device__ __forceinline__ CPtr<R> as_const_mem(const R *p) { return (CPtr<R>)p; }
-template <typename R> __device__ __forceinline__ R inp_at(CPtr<R> p, int mode, int b, int T, int k)
-{
-    if (mode == 0) return R(0);
-    return (mode == 1) ? p[b] : p[(size_t)b * T + k];
-}
-
 template <typename R> struct Eps;
 template <> struct Eps<float> { static constexpr float v = 1.1920929e-7f; };
 template <> struct Eps<double> { static constexpr double v = 2.220446049250313e-16; };
@@ -91,8 +77,7 @@ __device__ __forceinline__ void solve_one(const SolveArgs<R> &a, const int b, co
 {
     const int c8 = lane & 7, grp = lane >> 3;
     const int T = a.T;
-    const CPtr<R> tg = as_const_mem(a.t + (a.t_batched ? (size_t)b * T : 0));
-    const CPtr<R> meal_ = as_const_mem(a.meal), tvns_ = as_const_mem(a.tvns), gd_ = as_const_mem(a.gd);
+    const R *__restrict__ tg = a.t + (a.t_batched ? (size_t)b * T : 0);
     R *__restrict__ yb = a.y + (size_t)b * T * 6;
     R *__restrict__ tape = TAPE ? a.tape + (size_t)b * a.max_steps * 8 : nullptr;
     int *__restrict__ tseg = TAPE ? a.tape_seg + (size_t)b * a.max_steps : nullptr;
@@ -143,9 +128,9 @@ __device__ __forceinline__ void solve_one(const SolveArgs<R> &a, const int b, co
 
     for (; k + 1 < T && st == HODE_ST_OK; ++k) {
         const R t0 = tg[k], t1 = tg[k + 1];
-        const R m0 = inp_at<R>(meal_, a.meal_mode, b, T, k), m1 = inp_at<R>(meal_, a.meal_mode, b, T, k + 1);
-        const R v0 = inp_at<R>(tvns_, a.tvns_mode, b, T, k), v1 = inp_at<R>(tvns_, a.tvns_mode, b, T, k + 1);
-        const R d0 = inp_at<R>(gd_, a.gd_mode, b, T, k), d1 = inp_at<R>(gd_, a.gd_mode, b, T, k + 1);
+        const R m0 = inp_at(a.meal, a.meal_mode, b, T, k), m1 = inp_at(a.meal, a.meal_mode, b, T, k + 1);
+        const R v0 = inp_at(a.tvns, a.tvns_mode, b, T, k), v1 = inp_at(a.tvns, a.tvns_mode, b, T, k + 1);
+        const R d0 = inp_at(a.gd, a.gd_mode, b, T, k), d1 = inp_at(a.gd, a.gd_mode, b, T, k + 1);
         const R len = t1 - t0;
         if (!(len > R(0))) {                  // repeated grid time: copy the state
             y_put(Y);

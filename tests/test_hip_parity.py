@@ -491,6 +491,35 @@ def test_cfg2_forward_4096x241_fp32_properties(hode, g0):
     assert relnorm((g1 + g2).cpu().numpy(), gall.cpu().numpy()) < 1e-5
 
 
+def test_cfg3_adjoint_4096x241_is_linear_in_the_cotangent_and_follows_a_patient_permutation(hode, g0):
+    """BASELINE config[2] size, two more properties that need no oracle at full size.  The discrete adjoint is a LINEAR map of
+    the output cotangent for a fixed tape: adj(a g1 + b g2) = a adj(g1) + b adj(g2) (fp32: to rounding).  And the batch has no
+    order: permuting the patients permutes y and gx0 BITWISE (a trajectory does not see its neighbours, whichever workgroup,
+    wave slot or accumulation row it lands in) and leaves the parameter gradient unchanged up to the order of its fp32 sums."""
+    import bench
+    B = 4096
+    x0, t, meal, tv = (v.cuda() for v in bench.synth_cohort(B, 78))
+    nn, ode = bench.synth_weights(0).cuda(), bench.ODE_DEFAULT.cuda()
+    sol = hode.solve_fwd(x0, t, meal, tv, None, ode, nn, 64, 4, want_tape=True)
+    assert int(sol.status.max()) == 0
+    gen = torch.Generator("cuda").manual_seed(11)
+    g1 = torch.randn(B, 241, 6, device="cuda", generator=gen) / B
+    g2 = torch.randn(B, 241, 6, device="cuda", generator=gen) / B
+    gx1, gn1, _ = hode.solve_bwd(sol, g1)
+    gx2, gn2, _ = hode.solve_bwd(sol, g2)
+    gx12, gn12, _ = hode.solve_bwd(sol, (0.75 * g1 - 1.5 * g2).contiguous())
+    assert relnorm(gn12.cpu().numpy(), (0.75 * gn1 - 1.5 * gn2).cpu().numpy()) < 2e-5
+    assert relnorm(gx12.cpu().numpy(), (0.75 * gx1 - 1.5 * gx2).cpu().numpy()) < 2e-5
+    gx1b, gn1b, _ = hode.solve_bwd(sol, g1)
+    assert torch.equal(gx1, gx1b) and torch.equal(gn1, gn1b)             # and it is deterministic (no floating-point atomics)
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(2)).cuda()
+    solp = hode.solve_fwd(x0[perm].contiguous(), t, meal[perm].contiguous(), tv[perm].contiguous(), None, ode, nn, 64, 4, want_tape=True)
+    assert torch.equal(solp.y, sol.y[perm]) and torch.equal(solp.nsteps, sol.nsteps[perm])
+    gxp, gnp, _ = hode.solve_bwd(solp, g1[perm].contiguous())
+    assert torch.equal(gxp, gx1[perm])
+    assert relnorm(gnp.cpu().numpy(), gn1.cpu().numpy()) < 1e-5
+
+
 def test_training_step_is_graph_capturable(hode, golden_dir, g0):
     """include/hode.h promises: every entry point only enqueues work on the given stream (no allocation, no
     synchronisation), so a whole training step -- solve with tape, fused MSE, adjoint, clip+Adam -- can be

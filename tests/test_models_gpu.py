@@ -693,3 +693,51 @@ def test_train_step_is_bit_reproducible_run_to_run():
     b = hode.solve_bwd(sol, c, want_gode=True)
     for u, v in zip(a, b):
         assert torch.equal(u, v)
+
+
+def test_taped_solve_reports_failures_through_its_one_synchronisation(M, golden_dir, caplog):
+    """loss() / forward() under autograd look at the status array ONCE per solve (its maximum: zero in the common case, and then
+    neither the retry scan nor the warning scan runs).  A trajectory that runs into the pole of GLP1 / (EC_50 + GLP1) must still be
+    warned about -- reference models/hybrid_ode_nn.py:243-256 logs "ODE solver failed for batch {b}" and keeps the zero rows --,
+    counted by solve_failures(), and must not poison the gradients of the healthy trajectories."""
+    import logging
+    m = load_model(M, golden_dir, "cuda")
+    g = np.load(os.path.join(golden_dir, "g4_t61_pulses.npz"))
+    x0 = torch.tensor(g["x0"][:4]).cuda()
+    t = torch.tensor(g["t"][:21]).cuda()
+    u = {"meal": torch.tensor(g["meal"][:4, :21]).cuda(), "tVNS": torch.tensor(g["tvns"][:4, :21]).cuda()}
+    with torch.no_grad():
+        obs = m.forward(x0, t, u)
+    batch = {"initial_state": x0, "observations": obs, "time_points": t, "external_inputs": u}
+    with caplog.at_level(logging.WARNING):
+        m.zero_grad()
+        m.loss(batch, 0.0, 0.0, use_physics_loss=False).backward()
+    assert m.last_solve_info["worst_status"] == 0 and m.solve_failures() == 0
+    assert not [r for r in caplog.records if "ODE solver failed" in r.getMessage()]
+    g_ok = torch.cat([p.grad.reshape(-1) for p in m.nn_residual.parameters()]).clone()
+    assert bool(torch.isfinite(g_ok).all()) and float(g_ok.abs().max()) >= 0.0
+
+    bad = x0.clone()
+    bad[2, 3] = -50.0                                          # GLP1 = -EC_50: the Hill term's pole, an exact 0 / 0 in the first RHS
+    batch_bad = dict(batch, initial_state=bad)
+    caplog.clear()
+    with caplog.at_level(logging.WARNING):
+        m.zero_grad()
+        loss = m.loss(batch_bad, 0.0, 0.0, use_physics_loss=False)
+        loss.backward()
+    st = m.last_solve_info["status"].cpu().numpy()
+    assert m.last_solve_info["worst_status"] == int(st.max()) and st[2] != 0 and (np.delete(st, 2) == 0).all()
+    assert m.solve_failures() == 1
+    msgs = [r.getMessage() for r in caplog.records if "ODE solver failed" in r.getMessage()]
+    assert len(msgs) == 1 and "batch 2" in msgs[0]
+    g_bad = torch.cat([p.grad.reshape(-1) for p in m.nn_residual.parameters()])
+    assert bool(torch.isfinite(loss)) and bool(torch.isfinite(g_bad).all())
+
+    # forward() under autograd (the _SolveFn route) reports through the same key
+    m.fused_likelihood = False
+    caplog.clear()
+    with caplog.at_level(logging.WARNING):
+        y = m.forward(bad, t, u)
+    assert y.requires_grad and m.last_solve_info["worst_status"] != 0 and m.solve_failures() == 1
+    assert float(y[2, 1:].abs().max()) == 0.0                  # rows from the failure on stay zero
+    assert len([r for r in caplog.records if "ODE solver failed" in r.getMessage()]) == 1
