@@ -478,3 +478,42 @@ def test_ws_adjoint_slot_geometry_ragged_batches_vs_oracle(hode, B):
     # without ODE-constant gradients the big batch takes the two-trajectories-per-wave instantiation
     _, gnn2, _ = hode.solve_bwd(s, dev(c))
     assert relnorm(gnn2.cpu().numpy(), gno) < 1e-4
+
+
+def test_ws_adjoint_two_trajectories_per_wave_with_parameter_sets(hode):
+    """The two-trajectories-per-propagation-wave instantiation (more than 8 x 256 trajectories per parameter set, no ODE-constant
+    gradients) with MORE THAN ONE parameter set in the launch: the gradient rows of a workgroup belong to its set, the slot
+    dealing restarts per set.  Two sets x 2 100 patients in one launch against the two sets launched on their own: gx0 bitwise,
+    the per-set parameter gradients to the order of their fp32 sums; and a 24-patient sample of each set against the fp64 oracle."""
+    Tn, per = 13, 2100
+    rng = np.random.default_rng(17)
+    base = np.array([5.0, 60.0, 80.0, 10.0, 0.0, 1.0])
+    x0 = np.tile(base * (1 + 0.05 * rng.standard_normal((per, 6))), (2, 1))
+    t = np.arange(Tn) * (5.0 / 60.0)
+    meal = np.tile((rng.random((per, Tn)) < 0.2).astype(np.float64), (2, 1))
+    tv = np.zeros((2 * per, Tn))
+    nn0 = bench.synth_weights(0).numpy().astype(np.float64)
+    nn1 = nn0 * (1 + 0.1 * rng.standard_normal(nn0.shape))
+    ode0 = bench.ODE_DEFAULT.numpy().astype(np.float64)
+    ode1 = ode0 * (1 + 0.02 * rng.standard_normal(17))
+    nn2, ode2 = np.concatenate([nn0, nn1]), np.concatenate([ode0, ode1])
+    c = rng.standard_normal((2 * per, Tn, 6)) / (per * Tn * 6)
+    s = hode.solve_fwd(dev(x0), dev(t), dev(meal), dev(tv), None, dev(ode2), dev(nn2), H, L, want_tape=True, n_sets=2)
+    assert int(s.status.max()) == 0
+    gx, gnn, _ = hode.solve_bwd(s, dev(c))
+    P = nn0.size
+    assert gnn.numel() == 2 * P
+    for k, (nn_k, ode_k) in enumerate(((nn0, ode0), (nn1, ode1))):
+        sl = slice(k * per, (k + 1) * per)
+        sk = hode.solve_fwd(dev(x0[sl]), dev(t), dev(meal[sl]), dev(tv[sl]), None, dev(ode_k), dev(nn_k), H, L, want_tape=True)
+        assert torch.equal(sk.y, s.y[sl])
+        gxk, gnk, _ = hode.solve_bwd(sk, dev(c[sl]))
+        assert torch.equal(gxk, gx[sl])
+        assert relnorm(gnn[k * P:(k + 1) * P].cpu().numpy(), gnk.cpu().numpy()) < 1e-5
+        idx = np.sort(rng.choice(per, 24, replace=False)) + k * per
+        _, sto, _, gxo, _, _ = oracle_fwd_bwd(x0[idx], t, meal[idx], tv[idx], ode_k, nn_k, lambda y, lo, hi: c[idx[lo:hi]], rtol=1e-6, atol=1e-8,
+                                              dtype=np.float64, chunk=24)
+        assert int(sto.max()) == 0
+        assert max(relnorm(gx.cpu().numpy()[i], gxo[j]) for j, i in enumerate(idx)) < 1e-4
+    # the two sets' gradients differ (the launch did not hand one set's rows to the other)
+    assert relnorm(gnn[:P].cpu().numpy(), gnn[P:].cpu().numpy()) > 1e-2
