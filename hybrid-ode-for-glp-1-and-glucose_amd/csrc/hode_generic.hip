@@ -162,10 +162,11 @@ template <typename R, int NW = 1> struct RhsStream {
 // hundred trajectories).  NoAcc: the atomics of round 2 (K5, fp64, deeper networks).
 constexpr int kGenAccMats = 4;
 struct NoAcc {};
-struct TeamAcc {
+template <int RPW> struct TeamAccT {
+    static constexpr int kRows = RPW;          // rows of every hidden matrix this wave owns: 8 (H <= 8 NW) or 16 (H <= 16 NW)
     // four separate arrays, not one [4][8][2]: hipcc folds a switch over identical case bodies into a dynamically indexed access,
     // and a dynamically indexed register array lives in scratch
-    float m0[8][2], m1[8][2], m2[8][2], m3[8][2];
+    float m0[RPW][2], m1[RPW][2], m2[RPW][2], m3[RPW][2];
     // The gradients of everything that is NOT a hidden matrix -- first layer, output layer, every bias: 2 566 values for 5 x 128 --
     // were the other half of the adjoint's time as atomics (every team adds to the same 10 KB at every stage: 92 ms -> 46 ms for
     // 1 024 x 61 without them, 8.7 -> 6.7 ms for 32 x 61).  All waves of a team hold the same cotangents, so the pieces are dealt
@@ -177,7 +178,7 @@ struct TeamAcc {
     __device__ __forceinline__ void zero()
     {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) m0[u][0] = m0[u][1] = m1[u][0] = m1[u][1] = m2[u][0] = m2[u][1] = m3[u][0] = m3[u][1] = 0.f;
+        for (int u = 0; u < RPW; ++u) m0[u][0] = m0[u][1] = m1[u][0] = m1[u][1] = m2[u][0] = m2[u][1] = m3[u][0] = m3[u][1] = 0.f;
 #pragma unroll
         for (int u = 0; u < 6; ++u) e[u][0] = e[u][1] = 0.f;
     }
@@ -213,27 +214,18 @@ struct TeamAcc {
             if (vB) atomic_add(gb + lane + 64, e[0][1]);
         }
     }
-    // matrix l (wave-uniform, 0 .. kGenAccMats - 1) += p
-    __device__ __forceinline__ void add(int l, const float (&pa)[8], const float (&pb)[8])
+    // accumulators of the matrix at compile-time position SLOT (0 = the LAST hidden matrix, see rhs_vjp_stream), row u of this wave
+    template <int SLOT> __device__ __forceinline__ void fma(int u, float dj, float inA, float inB)
     {
-        if (l == 0) {
-#pragma unroll
-            for (int u = 0; u < 8; ++u) { m0[u][0] += pa[u]; m0[u][1] += pb[u]; }
-        } else if (l == 1) {
-#pragma unroll
-            for (int u = 0; u < 8; ++u) { m1[u][0] += pa[u]; m1[u][1] += pb[u]; }
-        } else if (l == 2) {
-#pragma unroll
-            for (int u = 0; u < 8; ++u) { m2[u][0] += pa[u]; m2[u][1] += pb[u]; }
-        } else {
-#pragma unroll
-            for (int u = 0; u < 8; ++u) { m3[u][0] += pa[u]; m3[u][1] += pb[u]; }
-        }
+        static_assert(SLOT >= 0 && SLOT < 4, "kGenAccMats");
+        float(&m)[RPW][2] = SLOT == 0 ? m0 : SLOT == 1 ? m1 : SLOT == 2 ? m2 : m3;
+        m[u][0] = __builtin_fmaf(dj, inA, m[u][0]);
+        m[u][1] = __builtin_fmaf(dj, inB, m[u][1]);
     }
-    __device__ __forceinline__ void flush_one(const float (&m)[8][2], float *__restrict__ gW, int H, int j0, int lane)
+    __device__ __forceinline__ void flush_one(const float (&m)[RPW][2], float *__restrict__ gW, int H, int j0, int lane)
     {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < RPW; ++u) {
             const int j = j0 + u;
             if (j < H) {
                 if (lane < H) atomic_add(gW + (size_t)j * H + lane, m[u][0]);
@@ -246,13 +238,16 @@ struct TeamAcc {
     {
         if (g == nullptr) return;
         flush_edge(n, g, part, lane);
-        const int nm = n.L - 1;
-        if (nm > 0) flush_one(m0, g + n.hid_off(0), n.H, j0, lane);
-        if (nm > 1) flush_one(m1, g + n.hid_off(1), n.H, j0, lane);
-        if (nm > 2) flush_one(m2, g + n.hid_off(2), n.H, j0, lane);
-        if (nm > 3) flush_one(m3, g + n.hid_off(3), n.H, j0, lane);
+        const int nm = n.L - 1;                            // slot i holds hidden matrix nm - 1 - i
+        if (nm > 0) flush_one(m0, g + n.hid_off(nm - 1), n.H, j0, lane);
+        if (nm > 1) flush_one(m1, g + n.hid_off(nm - 2), n.H, j0, lane);
+        if (nm > 2) flush_one(m2, g + n.hid_off(nm - 3), n.H, j0, lane);
+        if (nm > 3) flush_one(m3, g + n.hid_off(nm - 4), n.H, j0, lane);
     }
 };
+
+template <typename T> struct IsTeamAcc { static constexpr bool v = false; static constexpr int rows = 8; };
+template <int RPW> struct IsTeamAcc<TeamAccT<RPW>> { static constexpr bool v = true; static constexpr int rows = RPW; };
 
 template <typename R, bool GODE, bool GT, int NW = 1, typename ACC = NoAcc>
 __device__ __forceinline__ R rhs_vjp_stream(const StreamNet<R> &n, R *__restrict__ g, const OdeP<R> &o, R t, R tvns, R gde, R gd_in,
@@ -270,7 +265,8 @@ __device__ __forceinline__ R rhs_vjp_stream(const StreamNet<R> &n, R *__restrict
     // this wave's rows of every hidden matrix (multiples of 8: the chunked loads below), and who adds the non-matrix gradients
     const int rows_per = (((H + NW - 1) / NW) + 7) & ~7;
     const int j0 = (part * rows_per < H) ? part * rows_per : H, j1 = (j0 + rows_per < H) ? j0 + rows_per : H;
-    constexpr bool kAcc = std::is_same<ACC, TeamAcc>::value;
+    constexpr bool kAcc = IsTeamAcc<ACC>::v;
+    using TeamAcc = TeamAccT<IsTeamAcc<ACC>::rows>;       // (the edge-piece constants; the type itself only when kAcc)
     // biases, first and last layer: atomics of the team's first wave -- or, with register accumulators, dealt out over the waves
     R *__restrict__ gedge = (part == 0 && !kAcc) ? g : nullptr;
     // output layer
@@ -299,7 +295,8 @@ __device__ __forceinline__ R rhs_vjp_stream(const StreamNet<R> &n, R *__restrict
     dA = vA ? act_bwd(dA, hA, n.act) : R(0);
     dB = vB ? act_bwd(dB, hB, n.act) : R(0);
     // hidden matrices, last to first: matrix l maps h_l (rows 2l, 2l+1 of the record) to h_{l+1}
-    for (int l = L - 2; l >= 0; --l) {
+    // one hidden matrix; `slot` = the matrix's position counted from the LAST one, as a compile-time constant (TeamAcc only)
+    auto hidden_bwd = [&](const int l, auto slot) {
         const R inA = rec[(2 * l) * kWave + lane], inB = rec[(2 * l + 1) * kWave + lane];
         const R *__restrict__ W = n.Wh(l);
         R *__restrict__ gW = g ? g + n.hid_off(l) : nullptr;
@@ -347,16 +344,14 @@ __device__ __forceinline__ R rhs_vjp_stream(const StreamNet<R> &n, R *__restrict
             for (int w = 0; w < NW; ++w) { pA += xch[(w * 2 + 0) * kWave + lane]; pB += xch[(w * 2 + 1) * kWave + lane]; }
             __syncthreads();
         }
-        if constexpr (std::is_same<ACC, TeamAcc>::value) {
+        if constexpr (kAcc) {
             if (g) {
-                float pa[8], pb[8];                            // this wave's eight rows of dW += delta (x) h_in (masked lanes: h_in = 0)
+                // this wave's rows of dW += delta (x) h_in (masked lanes: h_in = 0), straight into the registers of `slot`
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
+                for (int u = 0; u < IsTeamAcc<ACC>::rows; ++u) {
                     const R dj = (j0 + u < j1) ? unit_bcast(dA, dB, (j0 + u < j1) ? j0 + u : 0) : R(0);
-                    pa[u] = dj * inA;
-                    pb[u] = dj * inB;
+                    acc.template fma<decltype(slot)::value>(u, dj, inA, inB);
                 }
-                acc.add(l, pa, pb);
             }
         } else if (g) {
             for (j = j0; j < j1; ++j) {
@@ -368,6 +363,23 @@ __device__ __forceinline__ R rhs_vjp_stream(const StreamNet<R> &n, R *__restrict
         }
         dA = vA ? act_bwd(pA, inA, n.act) : R(0);
         dB = vB ? act_bwd(pB, inB, n.act) : R(0);
+    };
+    if constexpr (kAcc) {
+        // The accumulators must be addressed by a COMPILE-TIME index.  With the matrix index a run-time value hipcc merges the four
+        // "which matrix" branches into one body that addresses the accumulators through a selected offset -- and an array with a
+        // dynamic offset lives in scratch: sixteen scratch_load / s_waitcnt vmcnt(0) / v_fmac / scratch_store round trips per
+        // matrix and stage (472 B of scratch; 79 % of the wave's time in waits, tools/pmc_generic.sh).  A fixed-trip loop over
+        // the POSITION of the matrix from the last one unrolls fully and makes that position a constant.
+#pragma unroll
+        for (int i = 0; i < kGenAccMats; ++i) {
+            if (i > L - 2) break;
+            if (i == 0) hidden_bwd(L - 2, std::integral_constant<int, 0>{});
+            else if (i == 1) hidden_bwd(L - 3, std::integral_constant<int, 1>{});
+            else if (i == 2) hidden_bwd(L - 4, std::integral_constant<int, 2>{});
+            else hidden_bwd(L - 5, std::integral_constant<int, 3>{});
+        }
+    } else {
+        for (int l = L - 2; l >= 0; --l) hidden_bwd(l, std::integral_constant<int, 0>{});
     }
     // first layer: input row [t, G, I, Glu, GLP1, GE, FFA, glp1 := GLP1, tvns]
     const R in[9] = {t, G, I, Glu, GLP1, GE, FFA, GLP1, tvns};
@@ -524,10 +536,10 @@ template <typename R> int launch_solve_fwd_generic(hipStream_t s, const SolveArg
 // the forward has just written them), gradients leave through atomics inside rhs_vjp_stream.
 // waves per trajectory in the generic adjoint: 16 for H > 64 (eight rows of a 128 x 128 matrix each = one chunk of loads;
 // 32 x 61 of the 5 x 128 network: 22.4 ms with one wave per trajectory, 10.6 with 8, 9.0 with 16), 8 up to H = 64 (4.4 / 5.8 ms)
-template <typename R, bool GODE, bool GD, int kGenTeam, bool ACCREG>
+template <typename R, bool GODE, bool GD, int kGenTeam, int ACCREG>      // ACCREG: accumulator rows per wave (8 / 16), 0 = atomics
 __global__ __launch_bounds__(64 * kGenTeam) void solve_bwd_generic_kernel(const AdjArgs<R> a, const int method, const int L)
 {
-    using Acc = std::conditional_t<ACCREG, TeamAcc, NoAcc>;
+    using Acc = std::conditional_t<ACCREG != 0, TeamAccT<ACCREG ? ACCREG : 8>, NoAcc>;
     Acc acc;
     int acc_set = -1;                                       // the parameter set the accumulators belong to
     __shared__ R rowsT[8 * kWave];
@@ -549,7 +561,7 @@ __global__ __launch_bounds__(64 * kGenTeam) void solve_bwd_generic_kernel(const 
         const int set = b / per_set;
         const StreamNet<R> n{a.nn_p + (size_t)set * a.P, a.H, L, a.act};
         R *__restrict__ g = a.gnn ? a.gnn + (size_t)set * a.P : nullptr;
-        if constexpr (ACCREG) {
+        if constexpr (ACCREG != 0) {
             if (set != acc_set) {                           // a workgroup's trajectories come set by set: flush when the set changes
                 if (acc_set >= 0) acc.flush(StreamNet<R>{a.nn_p + (size_t)acc_set * a.P, a.H, L, a.act}, a.gnn ? a.gnn + (size_t)acc_set * a.P : nullptr, j0_k, lane, part);
                 acc.zero();
@@ -615,12 +627,12 @@ __global__ __launch_bounds__(64 * kGenTeam) void solve_bwd_generic_kernel(const 
             }
         }
     }
-    if constexpr (ACCREG) {
+    if constexpr (ACCREG != 0) {
         if (acc_set >= 0) acc.flush(StreamNet<R>{a.nn_p + (size_t)acc_set * a.P, a.H, L, a.act}, a.gnn ? a.gnn + (size_t)acc_set * a.P : nullptr, j0_k, lane, part);
     }
 }
 
-template <typename R, int NW, bool ACCREG> static int launch_bwd_generic_t(hipStream_t s, const AdjArgs<R> &a, int L, int method)
+template <typename R, int NW, int ACCREG> static int launch_bwd_generic_t(hipStream_t s, const AdjArgs<R> &a, int L, int method)
 {
     // with register accumulators a workgroup flushes once: fewer, longer-lived workgroups (a few per CU) beat one per trajectory
     int blocks = a.B < 4096 ? a.B : 4096;
@@ -639,15 +651,14 @@ template <typename R, int NW, bool ACCREG> static int launch_bwd_generic_t(hipSt
 template <typename R> int launch_solve_bwd_generic(hipStream_t s, const AdjArgs<R> &a, int L, int method)
 {
     if constexpr (sizeof(R) == 4) {
-        // fp32, at most kGenAccMats hidden matrices: ALL parameter gradients accumulate in the team's registers (eight rows of every
-        // hidden matrix per wave, the edge pieces dealt out over the waves) and leave once per workgroup.
-        // Measured (5 x 128 / 5 x 64, T = 61, accumulators against atomics): B = 32: 7.3 against 9.0 ms / 5.2 against 4.1;
-        // B = 256: 12.2 against 31.2 / 7.2 against 24.9; B = 1 024: 48.8 against 135 / 28.9 against 99 -- the narrow network at
-        // the reference's batch keeps the atomics
-        if (L - 1 <= kGenAccMats && a.gnn != nullptr && (a.H > 64 || a.B > 128))
-            return a.H > 64 ? launch_bwd_generic_t<R, 16, true>(s, a, L, method) : launch_bwd_generic_t<R, 8, true>(s, a, L, method);
+        // fp32, at most kGenAccMats hidden matrices: ALL parameter gradients accumulate in the team's registers (the wave's rows of
+        // every hidden matrix, the edge pieces dealt out over the waves) and leave once per workgroup.  Teams of EIGHT waves also
+        // above 64 hidden units (sixteen rows per wave: 128 accumulator registers): a 16-wave workgroup is capped at 128 VGPRs per
+        // wave, which the 76 accumulators + the kernel's own ~60 registers do not fit (484 B of spills inside the stage loop).
+        if (L - 1 <= kGenAccMats && a.gnn != nullptr)
+            return a.H > 64 ? launch_bwd_generic_t<R, 8, 16>(s, a, L, method) : launch_bwd_generic_t<R, 8, 8>(s, a, L, method);
     }
-    return a.H > 64 ? launch_bwd_generic_t<R, 16, false>(s, a, L, method) : launch_bwd_generic_t<R, 8, false>(s, a, L, method);
+    return a.H > 64 ? launch_bwd_generic_t<R, 16, 0>(s, a, L, method) : launch_bwd_generic_t<R, 8, 0>(s, a, L, method);
 }
 
 template int launch_rhs_fwd_generic<float>(hipStream_t, const RhsArgs<float> &, int);
