@@ -61,6 +61,39 @@ template <typename R> struct StreamNet {
     __device__ __forceinline__ const R *bo() const { return Wo() + 6 * H; }
 };
 
+// Where the EDGE parameters -- first matrix, output matrix, every bias: (16 + L) H + 6 values, 11.5 KB for 5 x 128 -- are read from.
+//   EdgeFromParams  the flat parameter vector in global memory (K1 / K5: one evaluation per sample, nothing to amortise)
+//   EdgeImage       a copy in the workgroup's LDS, made once per trajectory (solve kernels).  These ~35 loads per evaluation were
+//                   issued again at every one of the 360+ evaluations of a trajectory -- hipcc cannot hoist them over the kernel's
+//                   stores -- and each group of them is an L2 round trip in front of a dependent computation.
+// Image layout: W1[H][9] | b1[H] | b_hidden[L-1][H] | Wout[6][H] | bout[6].
+template <typename R> struct EdgeFromParams {
+    const StreamNet<R> &n;
+    __device__ __forceinline__ const R *W1() const { return n.W1(); }
+    __device__ __forceinline__ const R *b1() const { return n.b1(); }
+    __device__ __forceinline__ const R *bh(int l) const { return n.bh(l); }
+    __device__ __forceinline__ const R *Wo() const { return n.Wo(); }
+    __device__ __forceinline__ const R *bo() const { return n.bo(); }
+};
+constexpr int kEdgeImageMax = (16 + 8) * 128 + 8;        // H <= 128, L <= 8
+template <typename R> struct EdgeImage {
+    const R *img;
+    int H, L;
+    __device__ __forceinline__ const R *W1() const { return img; }
+    __device__ __forceinline__ const R *b1() const { return img + 9 * H; }
+    __device__ __forceinline__ const R *bh(int l) const { return img + (10 + l) * H; }
+    __device__ __forceinline__ const R *Wo() const { return img + (9 + L) * H; }
+    __device__ __forceinline__ const R *bo() const { return img + (15 + L) * H; }
+    // cooperative copy by the whole workgroup (nthreads threads); the caller synchronises before the first use
+    static __device__ __forceinline__ void fill(R *__restrict__ img, const StreamNet<R> &n, int tid, int nthreads)
+    {
+        const int H = n.H, L = n.L;
+        for (int i = tid; i < 10 * H; i += nthreads) img[i] = n.p[i];                         // W1 | b1: contiguous
+        for (int i = tid; i < (L - 1) * H; i += nthreads) img[10 * H + i] = n.bh(i / H)[i % H];
+        for (int i = tid; i < 6 * H + 6; i += nthreads) img[(9 + L) * H + i] = n.Wo()[i];     // Wout | bout: contiguous
+    }
+};
+
 __device__ __forceinline__ float bcast_dyn(float v, int k) { return i2f(__builtin_amdgcn_readlane(f2i(v), k)); }
 __device__ __forceinline__ double bcast_dyn(double v, int k) { return lane_bcast(v, k); }
 // activation k of a layer whose units live two per lane (k < 64: register a of lane k; else register b of lane k - 64)
@@ -69,8 +102,8 @@ template <typename R> __device__ __forceinline__ R unit_bcast(R a, R b, int k) {
 // f(t, x, u) for an arbitrary network.  rec != nullptr: record h_1..h_L (two rows of 64 each) and the stage state (8 reals).
 // NW > 1: a team of NW waves evaluates the same f on identical data (see rhs_vjp_stream); the columns k of every hidden matrix
 // are split over the waves, partial sums exchanged through xch[NW][2][64] and added in wave order on every wave.
-template <typename R, int NW = 1>
-__device__ __forceinline__ R rhs_stream(const StreamNet<R> &n, const OdeP<R> &o, R t, R Y, R meal, R tvns, R gde, int lane,
+template <typename R, int NW = 1, typename EW = EdgeFromParams<R>>
+__device__ __forceinline__ R rhs_stream(const StreamNet<R> &n, const EW &ew, const OdeP<R> &o, R t, R Y, R meal, R tvns, R gde, int lane,
                                         R *__restrict__ rec, int part = 0, R *__restrict__ xch = nullptr)
 {
     const int H = n.H, L = n.L;
@@ -81,11 +114,11 @@ __device__ __forceinline__ R rhs_stream(const StreamNet<R> &n, const OdeP<R> &o,
     const bool vA = lane < H, vB = lane + 64 < H;
     const int jA = vA ? lane : 0, jB = vB ? lane + 64 : 0;              // clamped: masked lanes read a valid address
     const R in[9] = {t, G, I, Glu, GLP1, GE, FFA, GLP1, tvns};          // models/nn_residual.py:138-143
-    R hA = n.b1()[jA], hB = n.b1()[jB];
+    R hA = ew.b1()[jA], hB = ew.b1()[jB];
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
-        hA = rfma(n.W1()[jA * 9 + i], in[i], hA);
-        hB = rfma(n.W1()[jB * 9 + i], in[i], hB);
+        hA = rfma(ew.W1()[jA * 9 + i], in[i], hA);
+        hB = rfma(ew.W1()[jB * 9 + i], in[i], hB);
     }
     hA = vA ? act_f(hA, n.act) : R(0);
     hB = vB ? act_f(hB, n.act) : R(0);
@@ -94,7 +127,7 @@ __device__ __forceinline__ R rhs_stream(const StreamNet<R> &n, const OdeP<R> &o,
     const int k0 = (part * cols_per < H) ? part * cols_per : H, k1 = (k0 + cols_per < H) ? k0 + cols_per : H;
     for (int l = 0; l + 1 < L; ++l) {
         const R *__restrict__ rowA = n.Wh(l) + (size_t)jA * H, *__restrict__ rowB = n.Wh(l) + (size_t)jB * H;
-        R aA = (NW == 1) ? n.bh(l)[jA] : R(0), aB = (NW == 1) ? n.bh(l)[jB] : R(0);
+        R aA = (NW == 1) ? ew.bh(l)[jA] : R(0), aB = (NW == 1) ? ew.bh(l)[jB] : R(0);
         // chunks of 8 columns: 16 independent loads in flight, then the 16 FMAs (one load, one dependent FMA at a time left
         // a lone wave waiting out an L2 round trip per column: 21.9 ms per 32 x 61 forward of the 5 x 128 network, 7.7 ms now)
         int k = k0;
@@ -118,7 +151,7 @@ __device__ __forceinline__ R rhs_stream(const StreamNet<R> &n, const OdeP<R> &o,
             xch[(part * 2 + 0) * kWave + lane] = aA;
             xch[(part * 2 + 1) * kWave + lane] = aB;
             __syncthreads();
-            aA = n.bh(l)[jA]; aB = n.bh(l)[jB];
+            aA = ew.bh(l)[jA]; aB = ew.bh(l)[jB];
 #pragma unroll
             for (int w = 0; w < NW; ++w) { aA += xch[(w * 2 + 0) * kWave + lane]; aB += xch[(w * 2 + 1) * kWave + lane]; }
             __syncthreads();
@@ -129,24 +162,186 @@ __device__ __forceinline__ R rhs_stream(const StreamNet<R> &n, const OdeP<R> &o,
     }
     R p[6];
 #pragma unroll
-    for (int q = 0; q < 6; ++q) p[q] = n.Wo()[q * H + jA] * hA + n.Wo()[q * H + jB] * hB;     // h is 0 on masked lanes
+    for (int q = 0; q < 6; ++q) p[q] = ew.Wo()[q * H + jA] * hA + ew.Wo()[q * H + jB] * hB;     // h is 0 on masked lanes
     const R nn = wave_reduce6_to_lanes(p, lane);
     if (rec && lane < 8) rec[2 * L * kWave + lane] = Y;
-    const R bout = (c8 < 6) ? n.bo()[(c8 < 6) ? c8 : 0] : R(0);
+    const R bout = (c8 < 6) ? ew.bo()[(c8 < 6) ? c8 : 0] : R(0);
     return (c8 < 6) ? (mech + nn + bout) : R(0);
 }
 
-template <typename R, int NW = 1> struct RhsStream {
+// f(t, x, u) by a TEAM of NW waves, hidden layers split by OUTPUT ROWS (solve_fwd_generic_kernel, NW > 1, L >= 2).
+// The column split above makes every wave add up NW partial vectors per layer (2 NW LDS reads and adds per wave, two barriers): at 16
+// waves a wave issued ~1 100 instructions per evaluation for 128 useful FMAs, and four such waves share a SIMD's issue slots
+// (tools/pmc_generic.sh: the forward of 32 x 61 was issue-bound).  Here the activation vector lives in LDS (hb[2][128], zero beyond
+// H) and lane (r, c) = (lane >> 3, lane & 7) of wave w owns row 8 (w + NW blk) + r and the 16-column chunk c of it: 16 FMAs, a
+// 3-step sum over the eight lanes of the row, bias + activation, one 4-byte LDS write per row, ONE barrier per layer -- an
+// all-gather of eight finished outputs per wave instead of an all-reduce of 128 partial sums.  The first layer (9 inputs) and the
+// output layer (6 rows: lane (component, chunk), summed over the chunks into the replicated state layout) are computed by every
+// wave from identical data, so every wave ends with identical bits.
+constexpr int kHbStride = 128;
+constexpr int kGenAccMats = 4;       // hidden matrices whose weights (forward) / gradients (adjoint) a team can keep in registers
+// CC = columns per lane (16: H <= 128; 8: H <= 64, all eight lanes of a row busy).  NB > 0: the wave's NB row blocks of up to
+// kGenAccMats hidden matrices are REGISTER-RESIDENT (wres, loaded once per trajectory): 8-wave teams, NB = 2, CC = 16 for 128 hidden
+// units = 128 weight registers per lane and no weight load left in the evaluation; NB = 0 streams them from L2 as above.
+// CC consecutive weights of one matrix row.  fp32 rows that start on a 16-byte boundary (H a multiple of 4 and the parameter set
+// itself aligned: always for a single set) are read as dwordx4; left to itself hipcc vectorises the scalar loop with a peeled first
+// element -- dwordx4 loads at offsets 4, 20, 36 that straddle every 16-byte boundary (8.1 against 5.6 ms for the 1 024 x 61 forward).
+template <typename R, int CC> __device__ __forceinline__ void load_chunk(const R *__restrict__ wrow, R (&w)[CC], bool aligned16)
+{
+    if constexpr (sizeof(R) == 4) {
+        if (aligned16) {
+            typedef float __attribute__((ext_vector_type(4))) f4;
+            const f4 *__restrict__ q = reinterpret_cast<const f4 *>(wrow);
+#pragma unroll
+            for (int v = 0; v < CC / 4; ++v) {
+                const f4 x = q[v];
+                w[4 * v] = x.x; w[4 * v + 1] = x.y; w[4 * v + 2] = x.z; w[4 * v + 3] = x.w;
+            }
+            return;
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < CC; ++u) w[u] = wrow[u];
+}
+
+template <typename R, int CC, int NB> struct RowWeights { R w[kGenAccMats][NB > 0 ? NB : 1][CC]; };
+
+template <typename R, int NW, int CC, int NB>
+__device__ __forceinline__ void rows_preload(RowWeights<R, CC, NB> &rw, const StreamNet<R> &n, int lane, int part)
+{
+    if constexpr (NB > 0) {
+        const int H = n.H, k0 = CC * (lane & 7), r8 = lane >> 3;
+#pragma unroll
+        for (int l = 0; l < kGenAccMats; ++l) {
+#pragma unroll
+            for (int blk = 0; blk < NB; ++blk) {
+                const int row = 8 * (part + NW * blk) + r8;
+                const bool ok = l + 1 < n.L && row < H;
+                const R *__restrict__ wrow = n.Wh(ok ? l : 0) + (size_t)(ok ? row : 0) * H;
+#pragma unroll
+                for (int u = 0; u < CC; ++u) rw.w[l][blk][u] = (ok && k0 + u < H) ? wrow[(k0 + u < H) ? k0 + u : 0] : R(0);
+            }
+        }
+    }
+}
+
+template <typename R, int NW, typename EW, int CC, int NB>
+__device__ __forceinline__ R rhs_rows(const StreamNet<R> &n, const EW &ew, const RowWeights<R, CC, NB> &rw, const OdeP<R> &o, R t, R Y, R meal,
+                                      R tvns, R gde, int lane, R *__restrict__ rec, int part, R *__restrict__ hb)
+{
+    const int H = n.H, L = n.L;
+    const R G = lane_bcast(Y, 0), I = lane_bcast(Y, 1), Glu = lane_bcast(Y, 2), GLP1 = lane_bcast(Y, 3),
+            GE = lane_bcast(Y, 4), FFA = lane_bcast(Y, 5);
+    const int c8 = lane & 7, r8 = lane >> 3;
+    const R mech = mech_eval(o, G, I, Glu, GLP1, FFA, meal, gde, c8);
+    const bool vA = lane < H, vB = lane + 64 < H;
+    const int jA = vA ? lane : 0, jB = vB ? lane + 64 : 0;
+    const R in[9] = {t, G, I, Glu, GLP1, GE, FFA, GLP1, tvns};          // models/nn_residual.py:138-143
+    R hA = ew.b1()[jA], hB = ew.b1()[jB];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        hA = rfma(ew.W1()[jA * 9 + i], in[i], hA);
+        hB = rfma(ew.W1()[jB * 9 + i], in[i], hB);
+    }
+    hA = vA ? act_f(hA, n.act) : R(0);
+    hB = vB ? act_f(hB, n.act) : R(0);
+    // every wave writes the SAME h_1: a wave's own LDS writes are visible to its later reads, no barrier needed
+    hb[lane] = hA;
+    hb[kWave + lane] = hB;
+    if (rec) { rec[lane] = hA; rec[kWave + lane] = hB; }
+    const int k0 = CC * c8;                                  // this lane's column chunk [k0, k0 + CC)
+    // one hidden layer; slot = its index as a compile-time constant when its weights are register-resident (NB > 0), else unused
+    auto layer = [&](const int l, auto slot) {
+        const R *__restrict__ hin = hb + (l & 1) * kHbStride;
+        R *__restrict__ hout = hb + ((l + 1) & 1) * kHbStride;
+        R hc[CC];
+#pragma unroll
+        for (int u = 0; u < CC; ++u) hc[u] = hin[k0 + u];    // (zero beyond H)
+        auto finish = [&](R acc, int row, bool vr) {
+            acc = oct_allsum(acc);
+            const R v = act_f(acc + ew.bh(l)[vr ? row : 0], n.act);
+            if (c8 == 0 && vr) hout[row] = v;
+        };
+        if constexpr (NB > 0) {
+#pragma unroll
+            for (int blk = 0; blk < NB; ++blk) {
+                const int row = 8 * (part + NW * blk) + r8;
+                R acc = R(0);
+#pragma unroll
+                for (int u = 0; u < CC; ++u) acc = rfma(rw.w[decltype(slot)::value][blk][u], hc[u], acc);
+                finish(acc, row, row < H);
+            }
+        } else {
+            const R *__restrict__ W = n.Wh(l);
+            // vector path: whole chunks only (H a multiple of CC: a chunk lies inside the row or, clamped to column 0, is discarded)
+            const bool al16 = (H % CC) == 0 && (reinterpret_cast<uintptr_t>(W) & 15) == 0;      // wave-uniform
+            for (int row0 = 8 * part; row0 < H; row0 += 8 * NW) {
+                const int row = row0 + r8;
+                const bool vr = row < H;
+                const R *__restrict__ wr0 = W + (size_t)(vr ? row : 0) * H;
+                R w[CC];
+                if (al16) {
+                    load_chunk<R, CC>(wr0 + (k0 < H ? k0 : 0), w, true);
+                } else {
+#pragma unroll
+                    for (int u = 0; u < CC; ++u) w[u] = wr0[(k0 + u < H) ? k0 + u : 0];      // never past the row
+                }
+                R acc = R(0);
+#pragma unroll
+                for (int u = 0; u < CC; ++u) acc = rfma((k0 + u < H) ? w[u] : R(0), hc[u], acc);
+                finish(acc, row, vr);
+            }
+        }
+        __syncthreads();
+        if (rec) { rec[(2 * (l + 1)) * kWave + lane] = hout[lane]; rec[(2 * (l + 1) + 1) * kWave + lane] = hout[kWave + lane]; }
+    };
+    if constexpr (NB > 0) {
+        // (a fixed-trip loop, fully unrolled: the register-resident weights need a compile-time layer index)
+#pragma unroll
+        for (int i = 0; i < kGenAccMats; ++i) {
+            if (i + 1 >= L) break;
+            if (i == 0) layer(0, std::integral_constant<int, 0>{});
+            else if (i == 1) layer(1, std::integral_constant<int, 1>{});
+            else if (i == 2) layer(2, std::integral_constant<int, 2>{});
+            else layer(3, std::integral_constant<int, 3>{});
+        }
+    } else {
+        for (int l = 0; l + 1 < L; ++l) layer(l, std::integral_constant<int, 0>{});
+    }
+    // output layer: lane (component c8 < 6, chunk r8) takes 16 columns of row c8; group_sum8 adds the eight chunks and leaves the
+    // sum on every lane with that component -- the replicated layout of the state
+    const R *__restrict__ hf = hb + ((L - 1) & 1) * kHbStride;
+    const int q = (c8 < 6) ? c8 : 0, ko = 16 * r8;
+    R acc = R(0);
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const int k = ko + u;
+        acc = rfma((k < H) ? ew.Wo()[q * H + ((k < H) ? k : 0)] : R(0), hf[k], acc);
+    }
+    acc = (c8 < 6) ? acc : R(0);
+    const R nn = group_sum8(acc);
+    if (rec && lane < 8) rec[2 * L * kWave + lane] = Y;
+    const R bout = (c8 < 6) ? ew.bo()[q] : R(0);
+    __syncthreads();                                         // the next evaluation overwrites hb
+    return (c8 < 6) ? (mech + nn + bout) : R(0);
+}
+
+template <typename R, int NW = 1, typename EW = EdgeFromParams<R>, int CC = 16, int NB = 0> struct RhsStream {
     StreamNet<R> n;
+    EW ew;                  // where the edge parameters come from (the workgroup's LDS image in the solve kernels)
     const OdeP<R> &o;
     int lane;
     int part;               // this wave's index in its team (NW > 1: hode_generic.hip solve_fwd_generic_kernel)
-    R *xch;                 // the team's exchange area
+    R *xch;                 // the team's exchange area (column split: partial sums; row split: hb[2][128])
+    RowWeights<R, CC, NB> rw;   // row split with NB > 0: this wave's rows of the hidden matrices (rows_preload)
     __device__ __forceinline__ int slot_elems() const { return 2 * n.L * kWave + 8; }
     __device__ __forceinline__ R operator()(R ts, R Ys, R meal, R tvns, R gde, R *__restrict__ rec) const
     {
         // every wave of a team computes the same f; only the first one writes the stage record
-        return rhs_stream<R, NW>(n, o, ts, Ys, meal, tvns, gde, lane, part == 0 ? rec : nullptr, part, xch);
+        if constexpr (NW > 1) {
+            if (n.L >= 2) return rhs_rows<R, NW, EW, CC, NB>(n, ew, rw, o, ts, Ys, meal, tvns, gde, lane, part == 0 ? rec : nullptr, part, xch);
+        }
+        return rhs_stream<R, NW, EW>(n, ew, o, ts, Ys, meal, tvns, gde, lane, part == 0 ? rec : nullptr, part, xch);
     }
 };
 
@@ -160,7 +355,6 @@ template <typename R, int NW = 1> struct RhsStream {
 // 8 NW, L - 1 <= kGenAccMats): dW[j0 + u][lane], dW[j0 + u][lane + 64].  With them the hidden-matrix gradients leave the chip once
 // per workgroup instead of once per stage (280 KB of atomics per stage of the 5 x 128 network: what bound the adjoint above a few
 // hundred trajectories).  NoAcc: the atomics of round 2 (K5, fp64, deeper networks).
-constexpr int kGenAccMats = 4;
 struct NoAcc {};
 template <int RPW> struct TeamAccT {
     static constexpr int kRows = RPW;          // rows of every hidden matrix this wave owns: 8 (H <= 8 NW) or 16 (H <= 16 NW)
@@ -249,8 +443,8 @@ template <int RPW> struct TeamAccT {
 template <typename T> struct IsTeamAcc { static constexpr bool v = false; static constexpr int rows = 8; };
 template <int RPW> struct IsTeamAcc<TeamAccT<RPW>> { static constexpr bool v = true; static constexpr int rows = RPW; };
 
-template <typename R, bool GODE, bool GT, int NW = 1, typename ACC = NoAcc>
-__device__ __forceinline__ R rhs_vjp_stream(const StreamNet<R> &n, R *__restrict__ g, const OdeP<R> &o, R t, R tvns, R gde, R gd_in,
+template <typename R, bool GODE, bool GT, int NW = 1, typename ACC = NoAcc, typename EW = EdgeFromParams<R>>
+__device__ __forceinline__ R rhs_vjp_stream(const StreamNet<R> &n, const EW &ew, R *__restrict__ g, const OdeP<R> &o, R t, R tvns, R gde, R gd_in,
                                             bool use_gd, int lane, const R *__restrict__ rec, R kb, R &go, R *gt_out, int part,
                                             R *__restrict__ xch, ACC &acc)
 {
@@ -274,8 +468,8 @@ __device__ __forceinline__ R rhs_vjp_stream(const StreamNet<R> &n, R *__restrict
     R dA = R(0), dB = R(0);
 #pragma unroll
     for (int q = 0; q < 6; ++q) {
-        dA = rfma(n.Wo()[q * H + jA], lq[q], dA);
-        dB = rfma(n.Wo()[q * H + jB], lq[q], dB);
+        dA = rfma(ew.Wo()[q * H + jA], lq[q], dA);
+        dB = rfma(ew.Wo()[q * H + jB], lq[q], dB);
         if (gedge) {
             if (vA) atomic_add(gedge + n.out_off() + q * H + jA, lq[q] * hA);
             if (vB) atomic_add(gedge + n.out_off() + q * H + jB, lq[q] * hB);
@@ -407,7 +601,7 @@ __device__ __forceinline__ R rhs_vjp_stream(const StreamNet<R> &n, R *__restrict
     }
     R w[9];
 #pragma unroll
-    for (int i = 0; i < 9; ++i) w[i] = n.W1()[jA * 9 + i] * dA + n.W1()[jB * 9 + i] * dB;       // d is 0 on masked lanes
+    for (int i = 0; i < 9; ++i) w[i] = ew.W1()[jA * 9 + i] * dA + ew.W1()[jB * 9 + i] * dB;       // d is 0 on masked lanes
     const R p[6] = {w[1], w[2], w[3], w[4] + w[7], w[5], w[6]};                                   // GLP1 feeds inputs 4 and 7
     const R nn = wave_reduce6_to_lanes(p, lane);
     if constexpr (GT) *gt_out = wave_allsum(w[0]);
@@ -426,7 +620,7 @@ __global__ __launch_bounds__(256) void rhs_fwd_generic_kernel(const RhsArgs<R> a
     for (int s = blockIdx.x * 4 + wave; s < a.B; s += gridDim.x * 4) {
         const R Y = (lane < 6) ? a.x[(size_t)s * 6 + lane] : R(0);
         const R gde = a.gd ? gd_effect(o, a.gd[s]) : R(0);
-        const R F = rhs_stream<R>(n, o, a.t ? a.t[s] : R(0), Y, a.meal ? a.meal[s] : R(0), a.tvns ? a.tvns[s] : R(0), gde, lane, nullptr);
+        const R F = rhs_stream<R>(n, EdgeFromParams<R>{n}, o, a.t ? a.t[s] : R(0), Y, a.meal ? a.meal[s] : R(0), a.tvns ? a.tvns[s] : R(0), gde, lane, nullptr);
         if (lane < 6) a.out[(size_t)s * 6 + lane] = F;
     }
 }
@@ -447,11 +641,11 @@ __global__ __launch_bounds__(256) void rhs_bwd_generic_kernel(const RhsArgs<R> a
         const R kb = (lane < 6) ? a.gout[(size_t)s * 6 + lane] : R(0);
         const R t = a.t ? a.t[s] : R(0), tvns = a.tvns ? a.tvns[s] : R(0), gdv = a.gd ? a.gd[s] : R(0);
         const R gde = a.gd ? gd_effect(o, gdv) : R(0);
-        (void)rhs_stream<R>(n, o, t, Y, a.meal ? a.meal[s] : R(0), tvns, gde, lane, rec);
+        (void)rhs_stream<R>(n, EdgeFromParams<R>{n}, o, t, Y, a.meal ? a.meal[s] : R(0), tvns, gde, lane, rec);
         __builtin_amdgcn_wave_barrier();
         R gt;
         NoAcc na;
-        const R Z = rhs_vjp_stream<R, GODE, true>(n, a.gnn, o, t, tvns, gde, gdv, a.gd != nullptr, lane, rec, kb, go, &gt, 0, (R *)nullptr, na);
+        const R Z = rhs_vjp_stream<R, GODE, true>(n, EdgeFromParams<R>{n}, a.gnn, o, t, tvns, gde, gdv, a.gd != nullptr, lane, rec, kb, go, &gt, 0, (R *)nullptr, na);
         __builtin_amdgcn_wave_barrier();
         if (lane < 6) a.gx[(size_t)s * 6 + lane] = Z;
         if (a.gt && lane == 0) a.gt[s] = gt;
@@ -486,45 +680,59 @@ template <typename R> int launch_rhs_bwd_generic(hipStream_t s, const RhsArgs<R>
 // NW = 1 for batches that fill the chip with one wave per trajectory; the reference trains these shapes on 32 trajectories
 // (forward 7.6 ms for 32 x 61 of the 5 x 128 network with one wave each: 97 % of the chip idle).  The waves of a team write the
 // same y / tape values to the same addresses (benign: identical bits); the stage records are written by the first wave only.
-template <typename R, int METHOD, bool TAPE, bool GD, int NW>
+template <typename R, int METHOD, bool TAPE, bool GD, int NW, int CC, int NB>
 __global__ __launch_bounds__(64 * NW) void solve_fwd_generic_kernel(const SolveArgs<R> a)
 {
     __shared__ R rows[8 * kWave];
     __shared__ R cvec[8];
     __shared__ R ybuf[NW * (kWave + 8)];
-    __shared__ R xch[NW * 2 * kWave];
+    __shared__ R xch[(NW * 2 * kWave > 2 * kHbStride) ? NW * 2 * kWave : 2 * kHbStride];   // column split: partial sums; row split: hb[2][128]
     const int lane = threadIdx.x & 63;
     const int part = first_lane((int)(threadIdx.x >> 6));
     const int b = blockIdx.x;
     const int set = b / (a.B / a.n_sets);
+    for (int i = threadIdx.x; i < 2 * kHbStride; i += 64 * NW) xch[i] = R(0);      // rhs_rows: zero beyond H, for good
     tableau_rows_store<R>(rows, METHOD, threadIdx.x, 64 * NW);
     if (threadIdx.x < 8) cvec[threadIdx.x] = (R)kTableau[METHOD].c[threadIdx.x];
     OdeP<R> o;
     ode_load(o, a.ode_p + 17 * set);
+    __shared__ R edge_img[kEdgeImageMax];                // the edge parameters of this trajectory's set (EdgeImage)
+    const StreamNet<R> net{a.nn_p + (size_t)set * a.P, a.H, a.L, a.act};
+    EdgeImage<R>::fill(edge_img, net, threadIdx.x, 64 * NW);
     __syncthreads();
-    const RhsStream<R, NW> rhs{StreamNet<R>{a.nn_p + (size_t)set * a.P, a.H, a.L, a.act}, o, lane, part, xch};
+    RhsStream<R, NW, EdgeImage<R>, CC, NB> rhs{net, EdgeImage<R>{edge_img, a.H, a.L}, o, lane, part, xch, {}};
+    rows_preload<R, NW, CC, NB>(rhs.rw, net, lane, part);
     solve_one<R, METHOD, TAPE, GD>(a, b, rhs, o, rows, cvec, ybuf + part * (kWave + 8), lane);
 }
 
-template <typename R, int METHOD, int NW> static int launch_fwd_generic_t(hipStream_t s, const SolveArgs<R> &a)
+template <typename R, int METHOD, int NW, int CC = 16, int NB = 0> static int launch_fwd_generic_t(hipStream_t s, const SolveArgs<R> &a)
 {
     const bool tape = a.tape != nullptr, gd = a.gd_mode != 0;
     const dim3 grid(a.B), block(64 * NW);
     if (tape) {
-        if (gd) hipLaunchKernelGGL((solve_fwd_generic_kernel<R, METHOD, true, true, NW>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((solve_fwd_generic_kernel<R, METHOD, true, false, NW>), grid, block, 0, s, a);
+        if (gd) hipLaunchKernelGGL((solve_fwd_generic_kernel<R, METHOD, true, true, NW, CC, NB>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((solve_fwd_generic_kernel<R, METHOD, true, false, NW, CC, NB>), grid, block, 0, s, a);
     } else {
-        if (gd) hipLaunchKernelGGL((solve_fwd_generic_kernel<R, METHOD, false, true, NW>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((solve_fwd_generic_kernel<R, METHOD, false, false, NW>), grid, block, 0, s, a);
+        if (gd) hipLaunchKernelGGL((solve_fwd_generic_kernel<R, METHOD, false, true, NW, CC, NB>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((solve_fwd_generic_kernel<R, METHOD, false, false, NW, CC, NB>), grid, block, 0, s, a);
     }
     return hipGetLastError() == hipSuccess ? HODE_OK : HODE_ELAUNCH;
 }
 template <typename R, int METHOD> static int launch_fwd_generic_m(hipStream_t s, const SolveArgs<R> &a)
 {
-    // teams while one wave per trajectory would leave most SIMDs empty (1 024 of them): 8 columns of a 128-wide matrix per wave
-    if (a.B <= 128) return a.H > 64 ? launch_fwd_generic_t<R, METHOD, 16>(s, a) : launch_fwd_generic_t<R, METHOD, 8>(s, a);
-    if (a.B <= 512) return launch_fwd_generic_t<R, METHOD, 4>(s, a);
-    return launch_fwd_generic_t<R, METHOD, 1>(s, a);
+    // Teams of waves per trajectory, hidden layers split by rows (rhs_rows).  fp32 with at most kGenAccMats hidden matrices and a
+    // batch of one or two trajectories per CU: eight waves with their rows of every matrix in registers (one workgroup per CU).
+    // Larger batches, fp64, deeper networks: four waves (eight up to 256 trajectories) streaming the weights from L2.
+    // Measured, 5 x 128 / 5 x 64, T = 61, forward (ms): B = 32: 1.56 / 0.98 (round-3 column split: 4.7 / 1.9); 256: 1.59 / 1.00;
+    // 512: 3.10 resident against 3.57 streamed / 1.97 against 1.71; 1 024: 6.2 against 5.5 / 3.9 against 2.2 (one wave per
+    // trajectory, the policy until now: 10.6 / 4.9); 4 096: 24.6 against 22.0 / 15.4 against 7.8.
+    const bool narrow = a.H <= 64;
+    if constexpr (sizeof(R) == 4) {
+        if (a.L >= 2 && a.L - 1 <= kGenAccMats && a.B <= (narrow ? 256 : 512))
+            return narrow ? launch_fwd_generic_t<R, METHOD, 8, 8, 1>(s, a) : launch_fwd_generic_t<R, METHOD, 8, 16, 2>(s, a);
+    }
+    if (a.B <= 256) return narrow ? launch_fwd_generic_t<R, METHOD, 8, 8, 0>(s, a) : launch_fwd_generic_t<R, METHOD, 8, 16, 0>(s, a);
+    return narrow ? launch_fwd_generic_t<R, METHOD, 4, 8, 0>(s, a) : launch_fwd_generic_t<R, METHOD, 4, 16, 0>(s, a);
 }
 template <typename R> int launch_solve_fwd_generic(hipStream_t s, const SolveArgs<R> &a, int method)
 {
@@ -544,6 +752,8 @@ __global__ __launch_bounds__(64 * kGenTeam) void solve_bwd_generic_kernel(const 
     int acc_set = -1;                                       // the parameter set the accumulators belong to
     __shared__ R rowsT[8 * kWave];
     __shared__ R xch[kGenTeam * 2 * kWave];
+    __shared__ R edge_img[kEdgeImageMax];                   // the edge parameters of the current set (EdgeImage)
+    int img_set = -1;
     const int lane = threadIdx.x & 63;
     const int part = first_lane((int)(threadIdx.x >> 6));      // every wave of the team walks the tape; the matrix rows are split
     const int c8 = lane & 7, grp = lane >> 3;
@@ -561,6 +771,13 @@ __global__ __launch_bounds__(64 * kGenTeam) void solve_bwd_generic_kernel(const 
         const int set = b / per_set;
         const StreamNet<R> n{a.nn_p + (size_t)set * a.P, a.H, L, a.act};
         R *__restrict__ g = a.gnn ? a.gnn + (size_t)set * a.P : nullptr;
+        if (set != img_set) {                               // (every wave of the workgroup walks the same b: uniform branch)
+            __syncthreads();                                // nobody reads the previous set's image any more
+            EdgeImage<R>::fill(edge_img, n, threadIdx.x, 64 * kGenTeam);
+            __syncthreads();
+            img_set = set;
+        }
+        const EdgeImage<R> ew{edge_img, a.H, L};
         if constexpr (ACCREG != 0) {
             if (set != acc_set) {                           // a workgroup's trajectories come set by set: flush when the set changes
                 if (acc_set >= 0) acc.flush(StreamNet<R>{a.nn_p + (size_t)acc_set * a.P, a.H, L, a.act}, a.gnn ? a.gnn + (size_t)acc_set * a.P : nullptr, j0_k, lane, part);
@@ -611,7 +828,7 @@ __global__ __launch_bounds__(64 * kGenTeam) void solve_bwd_generic_kernel(const 
                 const R gdv = rfma(al, dd, d0);
                 R gde = R(0);
                 if constexpr (use_gd) gde = gd_effect(o, gdv);
-                const R Z = rhs_vjp_stream<R, GODE, false, kGenTeam, Acc>(n, g, o, ts, rfma(al, dv, v0), gde, gdv, use_gd, lane,
+                const R Z = rhs_vjp_stream<R, GODE, false, kGenTeam, Acc, EdgeImage<R>>(n, ew, g, o, ts, rfma(al, dv, v0), gde, gdv, use_gd, lane,
                                                                           stg + ((size_t)st * 6 + s) * kSlot, kb, go, nullptr, part, xch, acc);
                 ZZ = (grp == s) ? Z : ZZ;
             }
