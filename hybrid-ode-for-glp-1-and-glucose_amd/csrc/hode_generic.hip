@@ -461,6 +461,7 @@ __device__ __forceinline__ R rhs_vjp_stream(const StreamNet<R> &n, const EW &ew,
     const int j0 = (part * rows_per < H) ? part * rows_per : H, j1 = (j0 + rows_per < H) ? j0 + rows_per : H;
     constexpr bool kAcc = IsTeamAcc<ACC>::v;
     using TeamAcc = TeamAccT<IsTeamAcc<ACC>::rows>;       // (the edge-piece constants; the type itself only when kAcc)
+    R *__restrict__ dloc = kAcc ? xch + (NW * 2 + part * 2) * kWave : nullptr;       // this wave's delta slice (kernel: xch[NW * 4 * 64])
     // biases, first and last layer: atomics of the team's first wave -- or, with register accumulators, dealt out over the waves
     R *__restrict__ gedge = (part == 0 && !kAcc) ? g : nullptr;
     // output layer
@@ -492,6 +493,12 @@ __device__ __forceinline__ R rhs_vjp_stream(const StreamNet<R> &n, const EW &ew,
     // one hidden matrix; `slot` = the matrix's position counted from the LAST one, as a compile-time constant (TeamAcc only)
     auto hidden_bwd = [&](const int l, auto slot) {
         const R inA = rec[(2 * l) * kWave + lane], inB = rec[(2 * l + 1) * kWave + lane];
+        if constexpr (kAcc) {
+            // delta_{l+1} of this wave into ITS slice of LDS: the sixteen delta_j of the wave's rows then come back as two or four
+            // 16-byte broadcast reads instead of sixteen v_readlane from a run-time lane (select + readlane + copy each)
+            dloc[lane] = dA;
+            dloc[kWave + lane] = dB;
+        }
         const R *__restrict__ W = n.Wh(l);
         R *__restrict__ gW = g ? g + n.hid_off(l) : nullptr;
         if (gedge) {
@@ -517,7 +524,9 @@ __device__ __forceinline__ R rhs_vjp_stream(const StreamNet<R> &n, const EW &ew,
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const R dj = unit_bcast(dA, dB, j + u);        // a dead unit (ReLU, dj == 0) adds nothing
+                R dj;
+                if constexpr (kAcc) dj = dloc[j + u];          // (own write above: LDS is in order per wave)
+                else dj = unit_bcast(dA, dB, j + u);           // a dead unit (ReLU, dj == 0) adds nothing
                 pA = rfma(wA[u], dj, pA);
                 pB = rfma(wB[u], dj, pB);
             }
@@ -543,7 +552,7 @@ __device__ __forceinline__ R rhs_vjp_stream(const StreamNet<R> &n, const EW &ew,
                 // this wave's rows of dW += delta (x) h_in (masked lanes: h_in = 0), straight into the registers of `slot`
 #pragma unroll
                 for (int u = 0; u < IsTeamAcc<ACC>::rows; ++u) {
-                    const R dj = (j0 + u < j1) ? unit_bcast(dA, dB, (j0 + u < j1) ? j0 + u : 0) : R(0);
+                    const R dj = (j0 + u < j1) ? dloc[(j0 + u < j1) ? j0 + u : 0] : R(0);
                     acc.template fma<decltype(slot)::value>(u, dj, inA, inB);
                 }
             }
@@ -751,7 +760,7 @@ __global__ __launch_bounds__(64 * kGenTeam) void solve_bwd_generic_kernel(const 
     Acc acc;
     int acc_set = -1;                                       // the parameter set the accumulators belong to
     __shared__ R rowsT[8 * kWave];
-    __shared__ R xch[kGenTeam * 2 * kWave];
+    __shared__ R xch[kGenTeam * 4 * kWave];                  // partial sums [NW][2][64] | every wave's delta slice [NW][2][64]
     __shared__ R edge_img[kEdgeImageMax];                   // the edge parameters of the current set (EdgeImage)
     int img_set = -1;
     const int lane = threadIdx.x & 63;
