@@ -178,7 +178,12 @@ __device__ __forceinline__ R rhs_stream(const StreamNet<R> &n, const EW &ew, con
 // all-gather of eight finished outputs per wave instead of an all-reduce of 128 partial sums.  The first layer (9 inputs) and the
 // output layer (6 rows: lane (component, chunk), summed over the chunks into the replicated state layout) are computed by every
 // wave from identical data, so every wave ends with identical bits.
-constexpr int kHbStride = 128;
+constexpr int kHbStride = 160;       // 128 values + the skew below
+// Position of activation k in an LDS vector read in chunks of CC by eight lanes at a time: every chunk start moves 4 banks on
+// (CC = 16: chunk c starts at dword 20 c; CC = 8: the upper four chunks shift by 4), so the eight 16-byte reads of a ds_read_b128
+// fall into eight different bank quads.  Unskewed, chunk starts 16 c hit two bank quads: 68 % of the LDS cycles of the forward
+// were bank conflicts (tools/pmc_generic.sh).
+template <int CC> __device__ __forceinline__ int hx(int k) { return k + 4 * (k >> (CC == 16 ? 4 : 5)); }
 constexpr int kGenAccMats = 4;       // hidden matrices whose weights (forward) / gradients (adjoint) a team can keep in registers
 // CC = columns per lane (16: H <= 128; 8: H <= 64, all eight lanes of a row busy).  NB > 0: the wave's NB row blocks of up to
 // kGenAccMats hidden matrices are REGISTER-RESIDENT (wres, loaded once per trajectory): 8-wave teams, NB = 2, CC = 16 for 128 hidden
@@ -246,8 +251,8 @@ __device__ __forceinline__ R rhs_rows(const StreamNet<R> &n, const EW &ew, const
     hA = vA ? act_f(hA, n.act) : R(0);
     hB = vB ? act_f(hB, n.act) : R(0);
     // every wave writes the SAME h_1: a wave's own LDS writes are visible to its later reads, no barrier needed
-    hb[lane] = hA;
-    hb[kWave + lane] = hB;
+    hb[hx<CC>(lane)] = hA;
+    hb[hx<CC>(kWave + lane)] = hB;
     if (rec) { rec[lane] = hA; rec[kWave + lane] = hB; }
     const int k0 = CC * c8;                                  // this lane's column chunk [k0, k0 + CC)
     // one hidden layer; slot = its index as a compile-time constant when its weights are register-resident (NB > 0), else unused
@@ -256,11 +261,11 @@ __device__ __forceinline__ R rhs_rows(const StreamNet<R> &n, const EW &ew, const
         R *__restrict__ hout = hb + ((l + 1) & 1) * kHbStride;
         R hc[CC];
 #pragma unroll
-        for (int u = 0; u < CC; ++u) hc[u] = hin[k0 + u];    // (zero beyond H)
+        for (int u = 0; u < CC; ++u) hc[u] = hin[hx<CC>(k0) + u];    // (zero beyond H; a chunk is contiguous under the skew)
         auto finish = [&](R acc, int row, bool vr) {
             acc = oct_allsum(acc);
             const R v = act_f(acc + ew.bh(l)[vr ? row : 0], n.act);
-            if (c8 == 0 && vr) hout[row] = v;
+            if (c8 == 0 && vr) hout[hx<CC>(row)] = v;
         };
         if constexpr (NB > 0) {
 #pragma unroll
@@ -293,7 +298,7 @@ __device__ __forceinline__ R rhs_rows(const StreamNet<R> &n, const EW &ew, const
             }
         }
         __syncthreads();
-        if (rec) { rec[(2 * (l + 1)) * kWave + lane] = hout[lane]; rec[(2 * (l + 1) + 1) * kWave + lane] = hout[kWave + lane]; }
+        if (rec) { rec[(2 * (l + 1)) * kWave + lane] = hout[hx<CC>(lane)]; rec[(2 * (l + 1) + 1) * kWave + lane] = hout[hx<CC>(kWave + lane)]; }
     };
     if constexpr (NB > 0) {
         // (a fixed-trip loop, fully unrolled: the register-resident weights need a compile-time layer index)
@@ -316,7 +321,7 @@ __device__ __forceinline__ R rhs_rows(const StreamNet<R> &n, const EW &ew, const
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
         const int k = ko + u;
-        acc = rfma((k < H) ? ew.Wo()[q * H + ((k < H) ? k : 0)] : R(0), hf[k], acc);
+        acc = rfma((k < H) ? ew.Wo()[q * H + ((k < H) ? k : 0)] : R(0), hf[hx<CC>(k)], acc);
     }
     acc = (c8 < 6) ? acc : R(0);
     const R nn = group_sum8(acc);
@@ -689,8 +694,10 @@ template <typename R> int launch_rhs_bwd_generic(hipStream_t s, const RhsArgs<R>
 // NW = 1 for batches that fill the chip with one wave per trajectory; the reference trains these shapes on 32 trajectories
 // (forward 7.6 ms for 32 x 61 of the 5 x 128 network with one wave each: 97 % of the chip idle).  The waves of a team write the
 // same y / tape values to the same addresses (benign: identical bits); the stage records are written by the first wave only.
+// (second launch bound = waves per SIMD the register allocation must leave room for: 4 for the streaming kernels -- at 130 VGPRs, three
+//  waves per SIMD, the 1 024 x 61 forward of 5 x 128 took 7.3 ms instead of 5.5 -- and 2 with register-resident weights; fp64 unbounded)
 template <typename R, int METHOD, bool TAPE, bool GD, int NW, int CC, int NB>
-__global__ __launch_bounds__(64 * NW) void solve_fwd_generic_kernel(const SolveArgs<R> a)
+__global__ __launch_bounds__(64 * NW, (sizeof(R) == 8) ? 1 : (NB > 0 ? 2 : 4)) void solve_fwd_generic_kernel(const SolveArgs<R> a)
 {
     __shared__ R rows[8 * kWave];
     __shared__ R cvec[8];
