@@ -2,20 +2,22 @@
 // up to hidden width 128 and 8 hidden layers (reference configs/ablation_no_physics.yaml:11-12 trains nn_hidden 128,
 // nn_layers 5; models/nn_residual.py:28-98 builds any width / depth).
 //
-// The tuned kernels (hode_solve_fwd.hip, hode_solve_bwd.hip) keep a 4 x 64 network in registers: 211 weight registers
+// The tuned kernels (hode_solve_fwd.hip, hode_solve_bwd_ws.hip) keep a 4 x 64 network in registers: 211 weight registers
 // per lane, gradient accumulators in registers, matrices compiled in as template parameters.  A 5 x 128 network has
 // 67 k parameters (270 KB): it fits neither the register file of a wave nor the 160 KB of LDS.  So here
-//   * the mapping stays ONE TRAJECTORY PER WAVEFRONT, and every lane owns TWO hidden units, j and j + 64;
-//   * weights are STREAMED from L2 at every evaluation, natural PyTorch layout: in the forward product lane j walks
-//     its rows j and j + 64 while the activation h_k arrives by v_readlane; in the transposed product lane k reads
-//     W[j][k] and W[j][k + 64] -- 256 contiguous bytes per wave load;
-//   * parameter gradients leave through coalesced global atomics (dW[j][:] += delta_j * h[:], one 256-byte atomic
-//     wave-instruction per matrix row and half), skipped when delta_j is exactly zero (ReLU);
-//   * depth is a run-time loop, layer activations go straight to the stage tape (2 L rows of 64 + the state in 8 reals per stage).
-// It is built for the batches the reference trains such shapes with (32 patients x 61 grid points): the adjoint moves
-// ~280 KB of atomics per stage, which at the chip's ~1.3 TB/s of float atomics is 2-3 ms for that batch and grows
-// linearly with B x T.  The integrator, controller, tape format and state layout are those of the tuned path
-// (hode_solve_body.h); CPU restatement: oracle/hode_oracle_impl.h (HODE_MAXH 128, HODE_MAXL 8).
+//   * depth is a run-time loop, every lane owns TWO hidden units (j and j + 64) in the "natural" layout of a layer's activations,
+//     and the stage tape records 2 L rows of 64 + the state in 8 reals per stage;
+//   * K1 / K5 (one evaluation per sample) and one-wave solves walk the matrices in their PyTorch layout, h_k by v_readlane
+//     (rhs_stream / rhs_vjp_stream), parameter gradients through coalesced global atomics;
+//   * the SOLVE kernels give every trajectory a TEAM of 4 / 8 waves (one workgroup) -- a trajectory of such a network is one long
+//     chain of dependent evaluations, and the batches these shapes are trained on (32 windows) would leave the chip empty:
+//       forward  rhs_rows: hidden layers split by output rows, activations through LDS, one barrier per layer, the wave's rows
+//                register-resident for small batches, streamed from L2 (16-byte loads) for large ones;
+//       adjoint  rhs_vjp_stream with TeamAccT: the wave's rows of W^T delta as partial sums (LDS exchange), ALL parameter gradients
+//                in registers (compile-time indexed), one flush per workgroup and parameter set;
+//     the edge parameters (first / output matrix, biases) come from an LDS image (EdgeImage).
+// DESIGN.md section 4.6 has the measurements that led here.  The integrator, controller, tape format and state layout are those
+// of the tuned path (hode_solve_body.h); CPU restatement: oracle/hode_oracle_impl.h (HODE_MAXH 128, HODE_MAXL 8).
 #include "hode_solve_body.h"
 #include <type_traits>
 
@@ -690,10 +692,9 @@ template <typename R> int launch_rhs_bwd_generic(hipStream_t s, const RhsArgs<R>
 
 // ------------------------------------------------------------------------------------------ K2 + K3
 // A team of NW waves per trajectory.  Every wave runs the integration (solve_one) on identical data -- identical step-size
-// decisions, identical control flow -- and the team splits the columns of the hidden matrices inside the right-hand side.
-// NW = 1 for batches that fill the chip with one wave per trajectory; the reference trains these shapes on 32 trajectories
-// (forward 7.6 ms for 32 x 61 of the 5 x 128 network with one wave each: 97 % of the chip idle).  The waves of a team write the
-// same y / tape values to the same addresses (benign: identical bits); the stage records are written by the first wave only.
+// decisions, identical control flow -- and the team splits the rows of the hidden matrices inside the right-hand side (rhs_rows).
+// The waves of a team write the same y / tape values to the same addresses (benign: identical bits); the stage records are written
+// by the first wave only.
 // (second launch bound = waves per SIMD the register allocation must leave room for: 4 for the streaming kernels -- at 130 VGPRs, three
 //  waves per SIMD, the 1 024 x 61 forward of 5 x 128 took 7.3 ms instead of 5.5 -- and 2 with register-resident weights; fp64 unbounded)
 template <typename R, int METHOD, bool TAPE, bool GD, int NW, int CC, int NB>
@@ -756,10 +757,10 @@ template <typename R> int launch_solve_fwd_generic(hipStream_t s, const SolveArg
 }
 
 // ------------------------------------------------------------------------------------------ K4
-// Same walk over the tape as solve_bwd_kernel (hode_solve_bwd.hip); records are read from HBM with plain loads (L2 hits:
-// the forward has just written them), gradients leave through atomics inside rhs_vjp_stream.
-// waves per trajectory in the generic adjoint: 16 for H > 64 (eight rows of a 128 x 128 matrix each = one chunk of loads;
-// 32 x 61 of the 5 x 128 network: 22.4 ms with one wave per trajectory, 10.6 with 8, 9.0 with 16), 8 up to H = 64 (4.4 / 5.8 ms)
+// Same walk over the tape as solve_bwd_kernel (hode_solve_bwd.hip); records are read from HBM with plain loads (L2 hits: the
+// forward has just written them).  Teams of 8 waves (16 for the atomics variant above 64 hidden units); ACCREG: the team's
+// register accumulators (TeamAccT), else gradients leave through atomics inside rhs_vjp_stream (fp64, more than four hidden
+// matrices, no parameter gradient wanted).
 template <typename R, bool GODE, bool GD, int kGenTeam, int ACCREG>      // ACCREG: accumulator rows per wave (8 / 16), 0 = atomics
 __global__ __launch_bounds__(64 * kGenTeam) void solve_bwd_generic_kernel(const AdjArgs<R> a, const int method, const int L)
 {

@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 
 from oracle import oracle as O  # noqa: E402  (checker only)
 
-SHAPES = [(128, 5), (96, 6), (64, 5), (100, 2), (128, 8), (7, 5),
+SHAPES = [(128, 5), (96, 6), (64, 5), (100, 2), (128, 8), (7, 5), (100, 1),        # (100, 1): no hidden matrix, wider than a wave
           # widths that are not multiples of 16 INSIDE the register-resident envelope (H <= 64, L <= 4): the bounded weight
           # gathers of the row-block order (mlp_hidden_blk) and of the rotating output layer (out_rot_fill)
           (40, 3), (7, 2), (33, 4)]
@@ -161,6 +161,46 @@ def test_reference_ablation_shape_fp32_forward_adjoint_and_sets(hode, golden_dir
     g3x, g3n, _ = hode.solve_bwd(s3, dev(c[:3], dt))
     r3x, r3n, _ = O.solve_bwd(r3, c[:3])
     assert relnorm(g3x.cpu().numpy(), r3x) < 5e-5 and relnorm(g3n.cpu().numpy(), r3n) < 5e-5
+
+
+@pytest.mark.parametrize("H,L", [(128, 5), (96, 3), (100, 3), (64, 5), (40, 3), (7, 3), (100, 1)])
+def test_team_kernels_of_the_forward_agree_with_each_other_and_the_oracle(hode, golden_dir, g0, H, L):
+    """The forward solve of a generic network picks one of three team kernels by batch size (hode_generic.hip launch_fwd_generic_m):
+    eight waves with register-resident rows (small batches), eight or four waves streaming the rows from L2 (larger ones; 16-byte
+    loads when the width is a multiple of the chunk and the parameter set is 16-byte aligned, element loads otherwise).  All of them
+    evaluate the same sums in the same order, so a trajectory must come out BITWISE the same whichever kernel integrates it -- widths
+    that fill the chunks (128, 64), leave whole chunks empty (96, 40) or cut a chunk (100, 7); three parameter sets in one launch (the
+    second set's parameters start 8 bytes off a 16-byte boundary: the element-load path) -- and match the fp64 oracle."""
+    f32 = torch.float32
+    g = np.load(os.path.join(golden_dir, "g4_t61_pulses.npz"))
+    sel = np.arange(0, 61, 5)
+    t = g["t"][sel].astype(np.float64)
+    nn, ode = net(H, L, seed=3), g0["ode"].astype(np.float64)
+    B = 600                                                   # > 512: four waves, streamed
+    rng = np.random.default_rng(H)
+    x0 = g["x0"][rng.integers(0, 8, B)] * (1 + 0.02 * rng.standard_normal((B, 6)))
+    meal, tv = g["meal"][rng.integers(0, 8, B)][:, sel], np.zeros((B, sel.size))
+    big = hode.solve_fwd(dev(x0, f32), dev(t, f32), dev(meal, f32), dev(tv, f32), None, dev(ode, f32), dev(nn, f32), H, L, want_tape=True)
+    assert int(big.status.max()) == 0
+    for n_small in (5, 300):                                  # resident rows (L - 1 <= 4) / eight waves streamed or resident
+        sub = slice(17, 17 + n_small)
+        small = hode.solve_fwd(dev(x0[sub], f32), dev(t, f32), dev(meal[sub], f32), dev(tv[sub], f32), None, dev(ode, f32), dev(nn, f32), H, L)
+        assert torch.equal(small.y, big.y[sub]) and torch.equal(small.nsteps, big.nsteps[sub]), (H, L, n_small)
+    ref = O.solve(x0[:6], t, meal[:6], tv[:6], None, ode, nn, H, L, rtol=1e-10, atol=1e-12, dtype=np.float64)
+    assert rel(big.y[:6].cpu().numpy(), ref.y) < 1e-3        # north_star's fp32 bar (gain-0.5 layers: activations of O(10), 2e-4 measured)
+    # three parameter sets x 200 patients in one launch against the sets on their own (and the stage tape they leave: the adjoint)
+    nn3 = np.concatenate([nn, 0.7 * nn, 1.2 * nn])
+    ode3 = np.concatenate([ode, ode, ode])
+    s3 = hode.solve_fwd(dev(x0, f32), dev(t, f32), dev(meal, f32), dev(tv, f32), None, dev(ode3, f32), dev(nn3, f32), H, L, n_sets=3, want_tape=True)
+    c = rng.standard_normal((B, sel.size, 6)) / B
+    _, gnn3, _ = hode.solve_bwd(s3, dev(c, f32))
+    P = nn.size
+    for k, f in enumerate((1.0, 0.7, 1.2)):
+        sl = slice(200 * k, 200 * (k + 1))
+        sk = hode.solve_fwd(dev(x0[sl], f32), dev(t, f32), dev(meal[sl], f32), dev(tv[sl], f32), None, dev(ode, f32), dev(f * nn, f32), H, L, want_tape=True)
+        assert torch.equal(sk.y, s3.y[sl]), (H, L, k)
+        _, gk, _ = hode.solve_bwd(sk, dev(c[sl], f32))
+        assert relnorm(gnn3[k * P:(k + 1) * P].cpu().numpy(), gk.cpu().numpy()) < 2e-5
 
 
 def test_class_surface_with_the_ablation_network():
