@@ -521,13 +521,31 @@ __device__ __forceinline__ R rhs_vjp_stream(const StreamNet<R> &n, const EW &ew,
         // pass 2 only adds (dW += delta (x) h_in).
         R pA = R(0), pB = R(0);
         int j = j0;
+        // (unsigned column offsets on a running wave-uniform row pointer: two scalar adds and two loads per row.  With `int` columns
+        //  and row * H recomputed per row hipcc spent six scalar and two 64-bit vector instructions on every row's addresses --
+        //  a quarter of the instructions of a stage, and the adjoint is bound by what its waves issue)
+        // fp32: BUFFER loads -- descriptor of the matrix in four SGPRs, the lane's column as a 32-bit VGPR byte offset, the row as
+        // the instruction's scalar offset: one scalar add and two loads per row.  As flat global loads hipcc spent six scalar and two
+        // 64-bit vector instructions on every row's addresses (a quarter of a stage's instructions, and the adjoint is bound by what
+        // its waves issue); precomputed per-lane row offsets cost 32 VGPRs and spill.
+        const unsigned oA = (unsigned)jA * (unsigned)sizeof(R), oB = (unsigned)jB * (unsigned)sizeof(R);   // byte offsets of the lane's columns
+        unsigned roff = (unsigned)j0 * (unsigned)H * (unsigned)sizeof(R);                                   // byte offset of row j in the matrix
+        const unsigned rstride = (unsigned)H * (unsigned)sizeof(R);
+        auto ld = [&](unsigned o) -> R {
+            if constexpr (sizeof(R) == 4) {
+                const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<R *>(W), 0, (int)((unsigned)H * (unsigned)H * 4u), 0x00020000);
+                return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)o, (int)roff, 0));
+            } else {
+                return *reinterpret_cast<const R *>(reinterpret_cast<const char *>(W) + roff + o);
+            }
+        };
         for (; j + 8 <= j1; j += 8) {                          // eight rows at a time: 16 independent loads in flight
             R wA[8], wB[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const R *__restrict__ row = W + (size_t)(j + u) * H;
-                wA[u] = row[jA];                                // column jA / jB of row j: 256 contiguous bytes per wave
-                wB[u] = row[jB];
+                wA[u] = ld(oA);                                 // column jA / jB of row j: 256 contiguous bytes per wave
+                wB[u] = ld(oB);
+                roff += rstride;
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -540,9 +558,9 @@ __device__ __forceinline__ R rhs_vjp_stream(const StreamNet<R> &n, const EW &ew,
         }
         for (; j < j1; ++j) {
             const R dj = unit_bcast(dA, dB, j);
-            const R *__restrict__ row = W + (size_t)j * H;
-            pA = rfma(row[jA], dj, pA);
-            pB = rfma(row[jB], dj, pB);
+            pA = rfma(ld(oA), dj, pA);
+            pB = rfma(ld(oB), dj, pB);
+            roff += rstride;
         }
         if constexpr (NW > 1) {
             // partial sums of the team, added in wave order on every wave (same bits everywhere)
@@ -558,10 +576,8 @@ __device__ __forceinline__ R rhs_vjp_stream(const StreamNet<R> &n, const EW &ew,
             if (g) {
                 // this wave's rows of dW += delta (x) h_in (masked lanes: h_in = 0), straight into the registers of `slot`
 #pragma unroll
-                for (int u = 0; u < IsTeamAcc<ACC>::rows; ++u) {
-                    const R dj = (j0 + u < j1) ? dloc[(j0 + u < j1) ? j0 + u : 0] : R(0);
-                    acc.template fma<decltype(slot)::value>(u, dj, inA, inB);
-                }
+                for (int u = 0; u < IsTeamAcc<ACC>::rows; ++u)      // (rows beyond H: delta is zero there -- dloc holds all 128 entries)
+                    acc.template fma<decltype(slot)::value>(u, dloc[j0 + u], inA, inB);
             }
         } else if (g) {
             for (j = j0; j < j1; ++j) {
