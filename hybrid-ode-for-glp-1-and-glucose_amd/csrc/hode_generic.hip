@@ -453,7 +453,7 @@ template <int RPW> struct IsTeamAcc<TeamAccT<RPW>> { static constexpr bool v = t
 template <typename R, bool GODE, bool GT, int NW = 1, typename ACC = NoAcc, typename EW = EdgeFromParams<R>>
 __device__ __forceinline__ R rhs_vjp_stream(const StreamNet<R> &n, const EW &ew, R *__restrict__ g, const OdeP<R> &o, R t, R tvns, R gde, R gd_in,
                                             bool use_gd, int lane, const R *__restrict__ rec, R kb, R &go, R *gt_out, int part,
-                                            R *__restrict__ xch, ACC &acc)
+                                            R *__restrict__ xch, ACC &acc, int &xpar)
 {
     const int H = n.H, L = n.L;
     const R *__restrict__ sx = rec + 2 * L * kWave;            // the stage state: wave-uniform loads
@@ -468,7 +468,7 @@ __device__ __forceinline__ R rhs_vjp_stream(const StreamNet<R> &n, const EW &ew,
     const int j0 = (part * rows_per < H) ? part * rows_per : H, j1 = (j0 + rows_per < H) ? j0 + rows_per : H;
     constexpr bool kAcc = IsTeamAcc<ACC>::v;
     using TeamAcc = TeamAccT<IsTeamAcc<ACC>::rows>;       // (the edge-piece constants; the type itself only when kAcc)
-    R *__restrict__ dloc = kAcc ? xch + (NW * 2 + part * 2) * kWave : nullptr;       // this wave's delta slice (kernel: xch[NW * 4 * 64])
+    R *__restrict__ dloc = kAcc ? xch + (NW * 4 + part * 2) * kWave : nullptr;       // this wave's delta slice (kernel: xch[NW * 6 * 64])
     // biases, first and last layer: atomics of the team's first wave -- or, with register accumulators, dealt out over the waves
     R *__restrict__ gedge = (part == 0 && !kAcc) ? g : nullptr;
     // output layer
@@ -563,14 +563,18 @@ __device__ __forceinline__ R rhs_vjp_stream(const StreamNet<R> &n, const EW &ew,
             roff += rstride;
         }
         if constexpr (NW > 1) {
-            // partial sums of the team, added in wave order on every wave (same bits everywhere)
-            xch[(part * 2 + 0) * kWave + lane] = pA;
-            xch[(part * 2 + 1) * kWave + lane] = pB;
+            // partial sums of the team, added in wave order on every wave (same bits everywhere).  Two exchange areas used in turn
+            // (xpar: a toggle that runs on across layers AND stages): the writes of the next exchange go to the other area, so ONE
+            // barrier per layer is enough -- a wave can be at most one barrier ahead of the slowest reader of the area it writes
+            // next but one
+            R *__restrict__ xl = xch + xpar * (NW * 2 * kWave);
+            xpar ^= 1;
+            xl[(part * 2 + 0) * kWave + lane] = pA;
+            xl[(part * 2 + 1) * kWave + lane] = pB;
             __syncthreads();
             pA = R(0); pB = R(0);
 #pragma unroll
-            for (int w = 0; w < NW; ++w) { pA += xch[(w * 2 + 0) * kWave + lane]; pB += xch[(w * 2 + 1) * kWave + lane]; }
-            __syncthreads();
+            for (int w = 0; w < NW; ++w) { pA += xl[(w * 2 + 0) * kWave + lane]; pB += xl[(w * 2 + 1) * kWave + lane]; }
         }
         if constexpr (kAcc) {
             if (g) {
@@ -677,7 +681,8 @@ __global__ __launch_bounds__(256) void rhs_bwd_generic_kernel(const RhsArgs<R> a
         __builtin_amdgcn_wave_barrier();
         R gt;
         NoAcc na;
-        const R Z = rhs_vjp_stream<R, GODE, true>(n, EdgeFromParams<R>{n}, a.gnn, o, t, tvns, gde, gdv, a.gd != nullptr, lane, rec, kb, go, &gt, 0, (R *)nullptr, na);
+        int xpar = 0;                                            // (one wave per sample: no exchange)
+        const R Z = rhs_vjp_stream<R, GODE, true>(n, EdgeFromParams<R>{n}, a.gnn, o, t, tvns, gde, gdv, a.gd != nullptr, lane, rec, kb, go, &gt, 0, (R *)nullptr, na, xpar);
         __builtin_amdgcn_wave_barrier();
         if (lane < 6) a.gx[(size_t)s * 6 + lane] = Z;
         if (a.gt && lane == 0) a.gt[s] = gt;
@@ -784,9 +789,10 @@ __global__ __launch_bounds__(64 * kGenTeam) void solve_bwd_generic_kernel(const 
     Acc acc;
     int acc_set = -1;                                       // the parameter set the accumulators belong to
     __shared__ R rowsT[8 * kWave];
-    __shared__ R xch[kGenTeam * 4 * kWave];                  // partial sums [NW][2][64] | every wave's delta slice [NW][2][64]
+    __shared__ R xch[kGenTeam * 6 * kWave];                  // partial sums, two areas [2][NW][2][64] | every wave's delta slice [NW][2][64]
     __shared__ R edge_img[kEdgeImageMax];                   // the edge parameters of the current set (EdgeImage)
     int img_set = -1;
+    int xpar = 0;                                           // which of the two exchange areas the next layer writes (rhs_vjp_stream)
     const int lane = threadIdx.x & 63;
     const int part = first_lane((int)(threadIdx.x >> 6));      // every wave of the team walks the tape; the matrix rows are split
     const int c8 = lane & 7, grp = lane >> 3;
@@ -862,7 +868,7 @@ __global__ __launch_bounds__(64 * kGenTeam) void solve_bwd_generic_kernel(const 
                 R gde = R(0);
                 if constexpr (use_gd) gde = gd_effect(o, gdv);
                 const R Z = rhs_vjp_stream<R, GODE, false, kGenTeam, Acc, EdgeImage<R>>(n, ew, g, o, ts, rfma(al, dv, v0), gde, gdv, use_gd, lane,
-                                                                          stg + ((size_t)st * 6 + s) * kSlot, kb, go, nullptr, part, xch, acc);
+                                                                          stg + ((size_t)st * 6 + s) * kSlot, kb, go, nullptr, part, xch, acc, xpar);
                 ZZ = (grp == s) ? Z : ZZ;
             }
             lam += group_sum8(rowsT[7 * kWave + lane] * ZZ);
