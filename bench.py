@@ -271,6 +271,42 @@ def vi_step(dev, patients, samples=16):
             "peak_mem_gib": torch.cuda.max_memory_allocated(dev) / 2 ** 30}
 
 
+def generic_path(dev):
+    """The reference's largest configuration, nn_hidden 128 / nn_layers 5 (configs/ablation_no_physics.yaml:11-12), through the generic
+    kernels (csrc/hode_generic.hip): forward with tape + adjoint at the reference's batch (32 windows x 61
+    points) and at 1 024 x 61.  HIP events on the launch stream; secondary numbers, never the headline."""
+    import hode
+    Hg, Lg, Tg = 128, 5, 61
+    g = torch.Generator().manual_seed(Hg + Lg)
+    P = hode.n_params(Hg, Lg)
+    nn = torch.randn(P, generator=g) * (0.5 * (2.0 / (2 * Hg)) ** 0.5)
+    nn[-(6 * Hg + 6):] *= 0.1
+    nn, ode = nn.to(dev), ODE_DEFAULT.to(dev)
+    rows = []
+    for Bg in (32, 1024):
+        x0, t, meal, tv = (v.to(dev) for v in synth_cohort(Bg, 5))
+        t, meal, tv = t[:Tg].contiguous(), meal[:, :Tg].contiguous(), tv[:, :Tg].contiguous()
+        st = hode.solve_fwd(x0, t, meal, tv, None, ode, nn, Hg, Lg, want_tape=True)
+        gy = torch.randn(st.y.shape, device=dev, generator=torch.Generator(dev).manual_seed(1)) / st.y.numel()
+
+        def timed(fn, reps=3):
+            fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / reps
+        ms_f = timed(lambda: hode.solve_fwd(x0, t, meal, tv, None, ode, nn, Hg, Lg, want_tape=True, tape=st.tape))
+        ms_b = timed(lambda: hode.solve_bwd(st, gy))
+        rows.append({"patients": Bg, "grid_points": Tg, "forward_with_tape_ms": ms_f, "adjoint_ms": ms_b,
+                     "trajectories_per_s_train": Bg / (ms_f + ms_b) * 1e3, "trajectories_ok": int((st.status == 0).sum())})
+    return {"workload": "MLP 9 -> 128 x 5 -> 6 (67 k parameters), DP5(4), fp32, forward with tape + adjoint",
+            "kernels": "solve_fwd_generic_kernel / solve_bwd_generic_kernel: teams of 4-8 waves per trajectory", "cases": rows}
+
+
 def data_side(dev, B, cpu=True):
     """SURVEY 8f-3 leg: generate a B-subject 4GI cohort (5 h at 5 min, 2 meals, 10 % noise: the reference's
     data/generate4GI.py __main__ configuration) on the device, then cut and z-score the windows (31 / 15)."""
@@ -342,6 +378,7 @@ def main():
     ap.add_argument("--no-train", action="store_true")
     ap.add_argument("--no-data-side", action="store_true")
     ap.add_argument("--no-vi", action="store_true")
+    ap.add_argument("--no-generic", action="store_true", help="skip the generic-path (128 x 5 network) block")
     ap.add_argument("--vi-patients", type=int, default=8192, help="patients of the VI leg (BASELINE config 5: 8 192 per GPU x 16 draws)")
     ap.add_argument("--cohort", type=int, default=65536, help="subjects of the data-side leg (4GI generator + windows)")
     ap.add_argument("--no-zscore", action="store_true", help="skip the z-scored-regime leg (profiling: the headline kernel's "
@@ -551,6 +588,8 @@ def main():
             out["train_step"] = train
         if world == 1 and not args.no_vi:
             out["vi_step"] = vi_step(dev, args.vi_patients)
+        if world == 1 and not args.no_generic:
+            out["generic_path"] = generic_path(dev)
         if world == 1 and not args.no_data_side:
             out["data_side"] = data_side(dev, args.cohort, cpu=not args.no_cpu_baseline)
         if world == 1 and not args.no_cpu_baseline:

@@ -6,7 +6,7 @@ OUT=$R/gpurun_out/prof_lds
 rm -rf $OUT && mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-ARGS="--steps 3 --warmup 1 --train-steps 2 --no-cpu-baseline --no-vi --no-data-side"
+ARGS="--steps 3 --warmup 1 --train-steps 2 --no-cpu-baseline --no-vi --no-generic --no-data-side"
 for C in "SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS" "SQ_INST_CYCLES_VMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_INST_ANY"; do
   N=$(echo $C | tr ' ' '_' | cut -c1-30)
   rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_$N -- python3 $R/bench.py $ARGS > $OUT/log_$N.txt 2>&1 || echo "pmc $C failed"

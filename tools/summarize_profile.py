@@ -25,7 +25,7 @@ if len(stats) > 1:
              "the run, or the stale files -- the counters of different kernel versions would be averaged together")
 rows = list(csv.DictReader(open(stats[-1])))
 with open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w") as f:
-    f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 5 --train-steps 5 --no-cpu-baseline --no-vi --no-zscore --no-build\n")
+    f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 5 --train-steps 5 --no-cpu-baseline --no-vi --no-generic --no-zscore --no-build\n")
     f.write("kernel,calls,total_ns,avg_ns,pct,min_ns,max_ns\n")
     for r in rows[:18]:
         f.write(f"\"{short(r['Name'])[:90]}\",{r['Calls']},{r['TotalDurationNs']},{float(r['AverageNs']):.0f},{r['Percentage']},{r['MinNs']},{r['MaxNs']}\n")
