@@ -512,22 +512,42 @@ __device__ __forceinline__ float mlp_hidden_relu(const float (&w)[kMaxH], float 
 // every fp32 forward kernel of this library uses, so that they stay comparable bit for bit.
 // Hazards: h is a VALU result (the previous layer's v_max): four plain multiplications stand before the first DPP read; every
 // v_permlane*_swap reads accumulators at least two instructions old (the s_nops where nothing else fits).
+// Instruction selection (round 3): per rotation n ONE v_mov_b32_dpp materialises row_ror:n(h) and TWO v_pk_fma_f32 update the
+// accumulator pairs (a0, a1), (a2, a3) from the weight pairs (w0_n, w1_n), (w2_n, w3_n), both halves taking the low half of the
+// moved operand (op_sel_hi:[1,0,1]) -- 47 instructions per layer instead of 64 v_fmac_f32_dpp, 12.3 against 14.7 SIMD cycles per
+// rotation at two waves per SIMD (tools/ubench/inst_cost_ubench.hip: k_step_pk2 / k_step_dpp4).  Same products, same order per
+// accumulator, one rounding per FMA: bit-identical to the DPP form.
+// One asm statement per instruction group: the moved operand must be an asm OPERAND (a 64-bit pair cannot be named as its low half
+// for the 32-bit v_mov_b32_dpp inside one statement; naming a fixed pair such as v[0:1] and declaring it clobbered was tried: hipcc
+// then spills whatever lived there and reloads it -- with a full vmcnt wait -- inside the stage loop of the taping kernel).  The
+// s_nops hipcc puts between the statements are issue slots of the SIMD's other wave and cost nothing measurable.
+typedef float f2_t __attribute__((ext_vector_type(2)));
 template <bool RELU> __device__ __forceinline__ float mlp_hidden_blk(const float (&w)[kMaxH], float bias, float h)
 {
-    float a0, a1, a2, a3;
-#define HODE_BK_ROW(n) \
-    "v_fmac_f32_dpp %[a2], %[h], %[w2_" #n "] row_ror:" #n " row_mask:0xf bank_mask:0xf\n\t" \
-    "v_fmac_f32_dpp %[a3], %[h], %[w3_" #n "] row_ror:" #n " row_mask:0xf bank_mask:0xf\n\t" \
-    "v_fmac_f32_dpp %[a0], %[h], %[w0_" #n "] row_ror:" #n " row_mask:0xf bank_mask:0xf\n\t" \
-    "v_fmac_f32_dpp %[a1], %[h], %[w1_" #n "] row_ror:" #n " row_mask:0xf bank_mask:0xf\n\t"
-#define HODE_BK_W(n) [w0_##n] "v"(w[n]), [w1_##n] "v"(w[16 + n]), [w2_##n] "v"(w[32 + n]), [w3_##n] "v"(w[48 + n])
-#define HODE_BK_BODY(TAIL)                                                                                                    \
-    asm("v_mul_f32 %[a2], %[h], %[w2_0]\n\t"                                                                                  \
-        "v_mul_f32 %[a3], %[h], %[w3_0]\n\t"                                                                                  \
-        "v_mul_f32 %[a0], %[h], %[w0_0]\n\t"                                                                                  \
-        "v_mul_f32 %[a1], %[h], %[w1_0]\n\t"                                                                                  \
-        HODE_BK_ROW(1) HODE_BK_ROW(2) HODE_BK_ROW(3) HODE_BK_ROW(4) HODE_BK_ROW(5) HODE_BK_ROW(6) HODE_BK_ROW(7) HODE_BK_ROW(8)   \
-        HODE_BK_ROW(9) HODE_BK_ROW(10) HODE_BK_ROW(11) HODE_BK_ROW(12) HODE_BK_ROW(13) HODE_BK_ROW(14) HODE_BK_ROW(15)            \
+    f2_t a01, a23, hr;
+    // n = 0: the lane's own activation (no rotation); plain products start the sums (h is a fresh VALU result: these two
+    // instructions are also the wait states its first DPP read needs)
+    {
+        const f2_t w01 = {w[0], w[16]}, w23 = {w[32], w[48]};
+        f2_t hh;
+        hh.x = h;
+        asm("v_pk_mul_f32 %0, %2, %4 op_sel_hi:[1,0]\n\tv_pk_mul_f32 %1, %3, %4 op_sel_hi:[1,0]" : "=&v"(a01), "=&v"(a23) : "v"(w01), "v"(w23), "v"(hh));
+    }
+#define HODE_BK_STEP(n)                                                                                                        \
+    {                                                                                                                          \
+        float lo;                                                                                                              \
+        asm("v_mov_b32_dpp %0, %1 row_ror:" #n " row_mask:0xf bank_mask:0xf" : "=v"(lo) : "v"(h));                             \
+        hr.x = lo;                                                                                                             \
+        const f2_t w01 = {w[n], w[16 + n]}, w23 = {w[32 + n], w[48 + n]};                                                      \
+        asm("v_pk_fma_f32 %0, %2, %4, %0 op_sel_hi:[1,0,1]\n\tv_pk_fma_f32 %1, %3, %4, %1 op_sel_hi:[1,0,1]"                  \
+            : "+v"(a01), "+v"(a23) : "v"(w01), "v"(w23), "v"(hr));                                                             \
+    }
+    HODE_BK_STEP(1) HODE_BK_STEP(2) HODE_BK_STEP(3) HODE_BK_STEP(4) HODE_BK_STEP(5) HODE_BK_STEP(6) HODE_BK_STEP(7) HODE_BK_STEP(8)
+    HODE_BK_STEP(9) HODE_BK_STEP(10) HODE_BK_STEP(11) HODE_BK_STEP(12) HODE_BK_STEP(13) HODE_BK_STEP(14) HODE_BK_STEP(15)
+#undef HODE_BK_STEP
+    float a0 = a01.x, a1 = a01.y, a2 = a23.x, a3 = a23.y;
+#define HODE_BK_TAIL(TAIL)                                                                                                    \
+    asm("s_nop 1\n\t"                         /* (hipcc may have just COPIED an accumulator: a swap reads two-instruction-old data) */ \
         "v_permlane16_swap_b32 %[a2], %[a3]\n\t" /* a2 = [u2.q0 u3.q0 u2.q2 u3.q2]   a3 = [u2.q1 u3.q1 u2.q3 u3.q3] */         \
         "s_nop 0\n\t"                                                                                                         \
         "v_permlane16_swap_b32 %[a0], %[a1]\n\t" /* a0 = [u0.q0 u1.q0 u0.q2 u1.q2]   a1 = [u0.q1 u1.q1 u0.q3 u1.q3] */         \
@@ -537,14 +557,9 @@ template <bool RELU> __device__ __forceinline__ float mlp_hidden_blk(const float
         "v_permlane32_swap_b32 %[a0], %[a2]\n\t" /* a0 = q0+q1 of u0 u1 u2 u3, a2 = q2+q3 of u0 u1 u2 u3 (u_t in row t) */     \
         "v_add_f32 %[a0], %[a0], %[a2]\n\t"                                                                                   \
         "v_add_f32 %[a0], %[a0], %[bias]" TAIL                                                                                \
-        : [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2), [a3] "=&v"(a3)                                                      \
-        : [h] "v"(h), [bias] "v"(bias), HODE_BK_W(0), HODE_BK_W(1),                                                           \
-          HODE_BK_W(2), HODE_BK_W(3), HODE_BK_W(4), HODE_BK_W(5), HODE_BK_W(6), HODE_BK_W(7), HODE_BK_W(8), HODE_BK_W(9),      \
-          HODE_BK_W(10), HODE_BK_W(11), HODE_BK_W(12), HODE_BK_W(13), HODE_BK_W(14), HODE_BK_W(15));
-    if constexpr (RELU) { HODE_BK_BODY("\n\tv_max_f32 %[a0], 0, %[a0]") } else { HODE_BK_BODY("") }
-#undef HODE_BK_BODY
-#undef HODE_BK_W
-#undef HODE_BK_ROW
+        : [a0] "+v"(a0), [a1] "+v"(a1), [a2] "+v"(a2), [a3] "+v"(a3) : [bias] "v"(bias));
+    if constexpr (RELU) { HODE_BK_TAIL("\n\tv_max_f32 %[a0], 0, %[a0]") } else { HODE_BK_TAIL("") }
+#undef HODE_BK_TAIL
     return a0;
 }
 // acc[q] += sum_n row_ror:n(R[q]) * w[16 q + n], n ascending within each accumulator; R[] must be two wait states old

@@ -56,6 +56,18 @@
 #define B_SWAP_DEP(i) asm volatile("v_permlane32_swap_b32 %0, %1\n v_add_f32 %0, %0, %1" : "+v"(a[0]), "+v"(b[0]));
 #define B_FMA_SGPR(i) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a[i]) : "s"(it), "v"(y));
 
+// one "rotation step" of a hidden layer (four accumulators share the rotated activation): four DPP FMAs, or one DPP move + two
+// packed FMAs on accumulator / weight PAIRS (v_pk_fma_f32: both halves take the low half of the moved operand)
+#define B_STEP_DPP4(i) if (i < 4) asm volatile("v_fmac_f32_dpp %0, %4, %5 row_ror:3 row_mask:0xf bank_mask:0xf\n v_fmac_f32_dpp %1, %4, %6 row_ror:3 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f32_dpp %2, %4, %7 row_ror:3 row_mask:0xf bank_mask:0xf\n v_fmac_f32_dpp %3, %4, %8 row_ror:3 row_mask:0xf bank_mask:0xf" \
+        : "+v"(a[4 * i]), "+v"(a[4 * i + 1]), "+v"(a[4 * i + 2]), "+v"(a[4 * i + 3]) : "v"(x), "v"(b[4 * i]), "v"(b[4 * i + 1]), "v"(b[4 * i + 2]), "v"(b[4 * i + 3]));
+typedef float f2_t __attribute__((ext_vector_type(2)));
+#define B_STEP_PK2(i) if (i < 4) { f2_t hr; float lo; asm volatile("v_mov_b32_dpp %0, %1 row_ror:3 row_mask:0xf bank_mask:0xf" : "=v"(lo) : "v"(x)); hr.x = lo; \
+        f2_t a01 = {a[4 * i], a[4 * i + 1]}, a23 = {a[4 * i + 2], a[4 * i + 3]}, w01 = {b[4 * i], b[4 * i + 1]}, w23 = {b[4 * i + 2], b[4 * i + 3]}; \
+        asm volatile("v_pk_fma_f32 %0, %2, %4, %0 op_sel_hi:[1,0,1]\n v_pk_fma_f32 %1, %3, %4, %1 op_sel_hi:[1,0,1]" \
+        : "+v"(a01), "+v"(a23) : "v"(w01), "v"(w23), "v"(hr)); a[4 * i] = a01.x; a[4 * i + 1] = a01.y; a[4 * i + 2] = a23.x; a[4 * i + 3] = a23.y; }
+KERNEL(k_step_dpp4, B_STEP_DPP4, 8)
+KERNEL(k_step_pk2, B_STEP_PK2, 8)
 KERNEL(k_fma, B_FMA, 32)
 KERNEL(k_fmac_dpp, B_FMAC_DPP, 32)
 KERNEL(k_add_dpp, B_ADD_DPP, 32)
@@ -98,6 +110,7 @@ int main()
 {
     float *out; unsigned long long *st;
     (void)hipMalloc(&out, 4 * 256 * 1024); (void)hipMalloc(&st, 8 * 1024);
+    RUN(k_step_dpp4); RUN(k_step_pk2);
     RUN(k_fma); RUN(k_fmac_dpp); RUN(k_add_dpp); RUN(k_mov_dpp); RUN(k_swap16); RUN(k_swap32); RUN(k_readlane_use);
     RUN(k_readlane6_use); RUN(k_bcast_dpp6); RUN(k_cndmask); RUN(k_rcp); RUN(k_pkmul); RUN(k_fma_nop0); RUN(k_fma_nop1);
     RUN(k_max); RUN(k_mov); RUN(k_fma_dep); RUN(k_dpp_dep); RUN(k_swap_add_dep); RUN(k_fma_sgpr);
