@@ -80,49 +80,76 @@ __device__ __forceinline__ float ws_mech_vjp(const OdeP<float> &o, float G, floa
     return r;
 }
 
-// delta_prev = W^T delta from the LDS image (hode_device.h: wt_rot_store), reads issued two groups of four ahead of their use:
-// the propagation wave has no outer-product FMAs to put between a read and its first use, but it has the registers
-template <int G> __device__ __forceinline__ void ws_wt_group(const Vec4<float> (&w)[4], const float (&Rd)[4], float (&acc)[4])
+// delta_prev = W^T delta in the ROW-BLOCK order of the forward's hidden layer (hode_device.h mlp_hidden_blk), the transposed matrix
+// in an LDS image of its own (wt_blk_store below):
+//     img[l][n][lane (r, i)] = { W_l[16 r + ((i - n) & 15)][16 w + i] : w = 0..3 }            n = 0..15
+// so delta_{l+1} in its NATURAL layout (unit per lane) is the DPP operand as it is -- no row replication (rows_replicate: 9
+// instructions per matrix and trajectory) --, the 16-byte word of rotation n holds the two weight PAIRS of the four accumulators, and
+// a rotation is one v_mov_b32_dpp + two v_pk_fma_f32 (both halves take the low half of the moved operand).  The four accumulators
+// are added over the rows and transposed by the forward's 2 + 1 swaps and 3 adds.  55 vector instructions per matrix and trajectory
+// instead of 76 (rotating-operand order of wt_rot_store: 64 v_fmac_f32_dpp, one per weight); the reads are issued two groups of four
+// rotations ahead of their use as before: the propagation wave has no outer-product FMAs to put between a read and its first use.
+__device__ __forceinline__ void wt_blk_store(float *__restrict__ wt, const float *__restrict__ nn_p, int H, int NLm1, int tid, int nthreads)
 {
-    static_assert(G >= 0 && G < 4, "four groups of sixteen rotations");
-#define HODE_WS_TAIL                                                                                                            \
-        "v_fmac_f32_dpp %[a0], %[r], %[w4] row_ror:4 row_mask:0xf bank_mask:0xf\n\t"                                           \
-        "v_fmac_f32_dpp %[a1], %[r], %[w5] row_ror:5 row_mask:0xf bank_mask:0xf\n\t"                                           \
-        "v_fmac_f32_dpp %[a2], %[r], %[w6] row_ror:6 row_mask:0xf bank_mask:0xf\n\t"                                           \
-        "v_fmac_f32_dpp %[a3], %[r], %[w7] row_ror:7 row_mask:0xf bank_mask:0xf\n\t"                                           \
-        "v_fmac_f32_dpp %[a0], %[r], %[w8] row_ror:8 row_mask:0xf bank_mask:0xf\n\t"                                           \
-        "v_fmac_f32_dpp %[a1], %[r], %[w9] row_ror:9 row_mask:0xf bank_mask:0xf\n\t"                                           \
-        "v_fmac_f32_dpp %[a2], %[r], %[w10] row_ror:10 row_mask:0xf bank_mask:0xf\n\t"                                         \
-        "v_fmac_f32_dpp %[a3], %[r], %[w11] row_ror:11 row_mask:0xf bank_mask:0xf\n\t"                                         \
-        "v_fmac_f32_dpp %[a0], %[r], %[w12] row_ror:12 row_mask:0xf bank_mask:0xf\n\t"                                         \
-        "v_fmac_f32_dpp %[a1], %[r], %[w13] row_ror:13 row_mask:0xf bank_mask:0xf\n\t"                                         \
-        "v_fmac_f32_dpp %[a2], %[r], %[w14] row_ror:14 row_mask:0xf bank_mask:0xf\n\t"                                         \
-        "v_fmac_f32_dpp %[a3], %[r], %[w15] row_ror:15 row_mask:0xf bank_mask:0xf"
-#define HODE_WS_INS                                                                                                             \
-        [r] "v"(Rd[G]), [w0] "v"(w[0].v[0]), [w1] "v"(w[0].v[1]), [w2] "v"(w[0].v[2]), [w3] "v"(w[0].v[3]), [w4] "v"(w[1].v[0]), \
-          [w5] "v"(w[1].v[1]), [w6] "v"(w[1].v[2]), [w7] "v"(w[1].v[3]), [w8] "v"(w[2].v[0]), [w9] "v"(w[2].v[1]),              \
-          [w10] "v"(w[2].v[2]), [w11] "v"(w[2].v[3]), [w12] "v"(w[3].v[0]), [w13] "v"(w[3].v[1]), [w14] "v"(w[3].v[2]),         \
-          [w15] "v"(w[3].v[3])
-    if constexpr (G == 0) {
-        // the first group starts the four sums with products: no zeroed accumulators
-        asm("v_mul_f32 %[a0], %[r], %[w0]\n\t"
-            "v_mul_f32_dpp %[a1], %[r], %[w1] row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mul_f32_dpp %[a2], %[r], %[w2] row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mul_f32_dpp %[a3], %[r], %[w3] row_ror:3 row_mask:0xf bank_mask:0xf\n\t" HODE_WS_TAIL
-            : [a0] "=&v"(acc[0]), [a1] "=&v"(acc[1]), [a2] "=&v"(acc[2]), [a3] "=&v"(acc[3])
-            : HODE_WS_INS);
-    } else {
-        asm("v_fmac_f32 %[a0], %[r], %[w0]\n\t"
-            "v_fmac_f32_dpp %[a1], %[r], %[w1] row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_fmac_f32_dpp %[a2], %[r], %[w2] row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
-            "v_fmac_f32_dpp %[a3], %[r], %[w3] row_ror:3 row_mask:0xf bank_mask:0xf\n\t" HODE_WS_TAIL
-            : [a0] "+v"(acc[0]), [a1] "+v"(acc[1]), [a2] "+v"(acc[2]), [a3] "+v"(acc[3])
-            : HODE_WS_INS);
+    const float *Wl = nn_p + 9 * H + H;
+    for (int l = 0; l < NLm1; ++l) {
+        for (int e = tid; e < kMaxH * kMaxH; e += nthreads) {
+            const int w = e & 3, lane = (e >> 2) & 63, n = e >> 8;
+            const int i = lane & 15, r = lane >> 4;
+            const int row = 16 * r + ((i - n) & 15), col = 16 * w + i;
+            wt[(size_t)l * kMaxH * kMaxH + e] = (row < H && col < H) ? Wl[(size_t)row * H + col] : 0.f;
+        }
+        Wl += (size_t)H * H + H;
     }
-#undef HODE_WS_TAIL
-#undef HODE_WS_INS
 }
-// The sixteen 16-byte reads of a matrix are issued ahead of their use: on entry w0 / w1 hold the rows of groups 0 and 1 (loaded
+
+// rotations 4 G .. 4 G + 3 (the words w[0..3]) of one matrix for one trajectory: d = delta in the natural layout
+template <int G> __device__ __forceinline__ void ws_wt_group(const Vec4<float> (&w)[4], const float d, f2_t &a01, f2_t &a23)
+{
+    static_assert(G >= 0 && G < 4, "four groups of four rotations");
+#define HODE_WS_STEP(I, N)                                                                                                      \
+    {                                                                                                                           \
+        float lo;                                                                                                               \
+        asm("v_mov_b32_dpp %0, %1 row_ror:" #N " row_mask:0xf bank_mask:0xf" : "=v"(lo) : "v"(d));                              \
+        f2_t hr;                                                                                                                \
+        hr.x = lo;                                                                                                              \
+        const f2_t w01 = {w[I].v[0], w[I].v[1]}, w23 = {w[I].v[2], w[I].v[3]};                                                  \
+        asm("v_pk_fma_f32 %0, %2, %4, %0 op_sel_hi:[1,0,1]\n\tv_pk_fma_f32 %1, %3, %4, %1 op_sel_hi:[1,0,1]"                   \
+            : "+v"(a01), "+v"(a23) : "v"(w01), "v"(w23), "v"(hr));                                                              \
+    }
+    if constexpr (G == 0) {
+        // rotation 0 is the lane's own delta; products start the sums (and are the wait states the first DPP read of d needs)
+        const f2_t w01 = {w[0].v[0], w[0].v[1]}, w23 = {w[0].v[2], w[0].v[3]};
+        f2_t hh;
+        hh.x = d;
+        asm("v_pk_mul_f32 %0, %2, %4 op_sel_hi:[1,0]\n\tv_pk_mul_f32 %1, %3, %4 op_sel_hi:[1,0]" : "=&v"(a01), "=&v"(a23) : "v"(w01), "v"(w23), "v"(hh));
+        HODE_WS_STEP(1, 1) HODE_WS_STEP(2, 2) HODE_WS_STEP(3, 3)
+    } else if constexpr (G == 1) {
+        HODE_WS_STEP(0, 4) HODE_WS_STEP(1, 5) HODE_WS_STEP(2, 6) HODE_WS_STEP(3, 7)
+    } else if constexpr (G == 2) {
+        HODE_WS_STEP(0, 8) HODE_WS_STEP(1, 9) HODE_WS_STEP(2, 10) HODE_WS_STEP(3, 11)
+    } else {
+        HODE_WS_STEP(0, 12) HODE_WS_STEP(1, 13) HODE_WS_STEP(2, 14) HODE_WS_STEP(3, 15)
+    }
+#undef HODE_WS_STEP
+}
+// the four accumulators -> (W^T delta)[unit of the lane]: sum over the four 16-lane rows and transpose (row t <- unit 16 t + i)
+__device__ __forceinline__ float ws_wt_finish(const f2_t a01, const f2_t a23)
+{
+    float a0 = a01.x, a1 = a01.y, a2 = a23.x, a3 = a23.y;
+    asm("s_nop 1\n\t"
+        "v_permlane16_swap_b32 %[a2], %[a3]\n\t"
+        "s_nop 0\n\t"
+        "v_permlane16_swap_b32 %[a0], %[a1]\n\t"
+        "v_add_f32 %[a2], %[a2], %[a3]\n\t"
+        "v_add_f32 %[a0], %[a0], %[a1]\n\t"
+        "s_nop 1\n\t"
+        "v_permlane32_swap_b32 %[a0], %[a2]\n\t"
+        "v_add_f32 %[a0], %[a0], %[a2]"
+        : [a0] "+v"(a0), [a1] "+v"(a1), [a2] "+v"(a2), [a3] "+v"(a3));
+    return a0;
+}
+// The sixteen 16-byte reads of a matrix are issued ahead of their use: on entry w0 / w1 hold the words of groups 0 and 1 (loaded
 // while the PREVIOUS matrix -- or, for the first matrix of a stage, the previous iteration's tail -- was being worked on), groups
 // 2 and 3 follow into the buffer the group before them has freed, and on exit w0 / w1 hold groups 0 and 1 of `wt_next`: the
 // propagation wave is one long dependent chain, an LDS round trip per matrix is 3 x ~150 cycles of it.
@@ -134,73 +161,40 @@ __device__ __forceinline__ void ws_wt_preload(const float *__restrict__ wt, int 
 #pragma unroll
     for (int i = 0; i < 4; ++i) w1[i] = wt4[(4 + i) * kMaxH + lane];
 }
-// U = 1
-__device__ __forceinline__ void ws_wt_mul(const float *__restrict__ wt, const float *__restrict__ wt_next, int lane, const float (&d)[1],
-                                          float (&out)[1], Vec4<float> (&w0)[4], Vec4<float> (&w1)[4])
-{
-    const Vec4<float> *wt4 = reinterpret_cast<const Vec4<float> *>(wt), *nx4 = reinterpret_cast<const Vec4<float> *>(wt_next);
-    float Rd[4];
-    rows_replicate(d[0], Rd);
-    // rows 4 G .. 4 G + 3 of the image feed group G (r = 16 G + 4 i + c  ->  q = G, n = 4 i + c)
-    float acc[4];                                   // started by group 0
-    __builtin_amdgcn_sched_barrier(0);
-    ws_wt_group<0>(w0, Rd, acc);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) w0[i] = wt4[(8 + i) * kMaxH + lane];
-    __builtin_amdgcn_sched_barrier(0);
-    ws_wt_group<1>(w1, Rd, acc);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) w1[i] = wt4[(12 + i) * kMaxH + lane];
-    __builtin_amdgcn_sched_barrier(0);
-    ws_wt_group<2>(w0, Rd, acc);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) w0[i] = nx4[(0 + i) * kMaxH + lane];
-    __builtin_amdgcn_sched_barrier(0);
-    ws_wt_group<3>(w1, Rd, acc);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) w1[i] = nx4[(4 + i) * kMaxH + lane];
-    out[0] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
-}
-// U = 2: the same sixteen 16-byte reads feed both trajectories' products (half the LDS traffic per trajectory), and the two
+// U trajectories: the same sixteen 16-byte reads feed all of them (half the LDS traffic per trajectory at U = 2), and their
 // accumulator sets are independent instruction chains
-__device__ __forceinline__ void ws_wt_mul(const float *__restrict__ wt, const float *__restrict__ wt_next, int lane, const float (&d)[2],
-                                          float (&out)[2], Vec4<float> (&w0)[4], Vec4<float> (&w1)[4])
+template <int U>
+__device__ __forceinline__ void ws_wt_mul(const float *__restrict__ wt, const float *__restrict__ wt_next, int lane, const float (&d)[U],
+                                          float (&out)[U], Vec4<float> (&w0)[4], Vec4<float> (&w1)[4])
 {
     const Vec4<float> *wt4 = reinterpret_cast<const Vec4<float> *>(wt), *nx4 = reinterpret_cast<const Vec4<float> *>(wt_next);
-    float Ra[4], Rb[4];
-    rows_replicate(d[0], Ra);
-    rows_replicate(d[1], Rb);
-    float aa[4], ab[4];                             // started by group 0
+    f2_t a01[U], a23[U];                            // started by group 0
     __builtin_amdgcn_sched_barrier(0);
-    ws_wt_group<0>(w0, Ra, aa);
-    ws_wt_group<0>(w0, Rb, ab);
+#pragma unroll
+    for (int u = 0; u < U; ++u) ws_wt_group<0>(w0, d[u], a01[u], a23[u]);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < 4; ++i) w0[i] = wt4[(8 + i) * kMaxH + lane];
     __builtin_amdgcn_sched_barrier(0);
-    ws_wt_group<1>(w1, Ra, aa);
-    ws_wt_group<1>(w1, Rb, ab);
+#pragma unroll
+    for (int u = 0; u < U; ++u) ws_wt_group<1>(w1, d[u], a01[u], a23[u]);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < 4; ++i) w1[i] = wt4[(12 + i) * kMaxH + lane];
     __builtin_amdgcn_sched_barrier(0);
-    ws_wt_group<2>(w0, Ra, aa);
-    ws_wt_group<2>(w0, Rb, ab);
+#pragma unroll
+    for (int u = 0; u < U; ++u) ws_wt_group<2>(w0, d[u], a01[u], a23[u]);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < 4; ++i) w0[i] = nx4[(0 + i) * kMaxH + lane];
     __builtin_amdgcn_sched_barrier(0);
-    ws_wt_group<3>(w1, Ra, aa);
-    ws_wt_group<3>(w1, Rb, ab);
+#pragma unroll
+    for (int u = 0; u < U; ++u) ws_wt_group<3>(w1, d[u], a01[u], a23[u]);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < 4; ++i) w1[i] = nx4[(4 + i) * kMaxH + lane];
-    out[0] = (aa[0] + aa[1]) + (aa[2] + aa[3]);
-    out[1] = (ab[0] + ab[1]) + (ab[2] + ab[3]);
+#pragma unroll
+    for (int u = 0; u < U; ++u) out[u] = ws_wt_finish(a01[u], a23[u]);
 }
 
 }  // namespace
@@ -316,7 +310,7 @@ __global__ __launch_bounds__(64 * kWsWaves) void solve_bwd_ws_kernel(const AdjAr
                         *__restrict__ const tvns_ = a.tvns, *__restrict__ const gd_ = a.gd, *__restrict__ const stage_ = a.tape_stage;
     const int *__restrict__ const seg_ = a.tape_seg, *__restrict__ const nsteps_ = a.nsteps, *__restrict__ const status_ = a.status;
 
-    wt_rot_store<R>(wt, nn_set, a.H, NM, threadIdx.x, 64 * kWsWaves);
+    wt_blk_store(wt, nn_set, a.H, NM, threadIdx.x, 64 * kWsWaves);
     tableau_rowsT_store<R>(rowsT, method, threadIdx.x, 64 * kWsWaves);
     if (threadIdx.x < 2 * 16) tags[threadIdx.x] = 0;
     if (threadIdx.x == 0) *niter = 0;
@@ -540,7 +534,7 @@ __global__ __launch_bounds__(64 * kWsWaves) void solve_bwd_ws_kernel(const AdjAr
                     for (int u = 0; u < U; ++u) dp[u] = d[u] * 0.5f;
                 } else {
                     // (the matrix after this one: l - 2, or -- behind the last -- the first matrix of the next stage)
-                    ws_wt_mul(wt + (size_t)(l - 1) * kMaxH * kMaxH, wt + (size_t)(l >= 2 ? l - 2 : NM - 1) * kMaxH * kMaxH, lane, d, dp, wq0, wq1);
+                    ws_wt_mul<U>(wt + (size_t)(l - 1) * kMaxH * kMaxH, wt + (size_t)(l >= 2 ? l - 2 : NM - 1) * kMaxH * kMaxH, lane, d, dp, wq0, wq1);
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
