@@ -199,12 +199,35 @@ __device__ __forceinline__ void ws_wt_mul(const float *__restrict__ wt, const fl
 
 }  // namespace
 
+// gw[2 n], gw[2 n + 1] += (D01, D23) * row_ror:n(hn): the sixteen rotations of one outer-product update (see ws_acc_slot)
+__device__ __forceinline__ void ws_outer_blk(f2_t (&gw)[kMaxH / 2], const f2_t D01, const f2_t D23, const float hn)
+{
+    {
+        f2_t hh;
+        hh.x = hn;
+        asm("v_pk_fma_f32 %0, %2, %4, %0 op_sel_hi:[1,0,1]\n\tv_pk_fma_f32 %1, %3, %4, %1 op_sel_hi:[1,0,1]"
+            : "+v"(gw[0]), "+v"(gw[1]) : "v"(D01), "v"(D23), "v"(hh));
+    }
+#define HODE_WS_OSTEP(N)                                                                                                        \
+    {                                                                                                                           \
+        float lo;                                                                                                               \
+        asm("v_mov_b32_dpp %0, %1 row_ror:" #N " row_mask:0xf bank_mask:0xf" : "=v"(lo) : "v"(hn));                             \
+        f2_t hr;                                                                                                                \
+        hr.x = lo;                                                                                                              \
+        asm("v_pk_fma_f32 %0, %2, %4, %0 op_sel_hi:[1,0,1]\n\tv_pk_fma_f32 %1, %3, %4, %1 op_sel_hi:[1,0,1]"                   \
+            : "+v"(gw[2 * N]), "+v"(gw[2 * N + 1]) : "v"(D01), "v"(D23), "v"(hr));                                              \
+    }
+    HODE_WS_OSTEP(1) HODE_WS_OSTEP(2) HODE_WS_OSTEP(3) HODE_WS_OSTEP(4) HODE_WS_OSTEP(5) HODE_WS_OSTEP(6) HODE_WS_OSTEP(7) HODE_WS_OSTEP(8)
+    HODE_WS_OSTEP(9) HODE_WS_OSTEP(10) HODE_WS_OSTEP(11) HODE_WS_OSTEP(12) HODE_WS_OSTEP(13) HODE_WS_OSTEP(14) HODE_WS_OSTEP(15)
+#undef HODE_WS_OSTEP
+}
+
 // Accumulation wave AJ: matrix AJ % (NL-1), rank AJ / (NL-1) among that matrix's waves; slot t belongs to the wave of rank
 // t % (waves of the matrix); waves 4..7 also keep the first / last layer gradients of the slots t with t % 4 == AJ - 4.
 // One slot (compile-time t: every LDS address is a base register + an immediate), then the next one.
 template <int NL, int U, int AJ, int T0>
 __device__ __forceinline__ void ws_acc_slot(const float *__restrict__ recs, const float *__restrict__ hbase, const int mytag, const int lane,
-                                            float (&gw)[kMaxH], float &gb, float (&ge)[17])
+                                            f2_t (&gw)[kMaxH / 2], float &gb, float (&ge)[17])
 {
     constexpr int NM = NL - 1, NT = kWsP * U;
     constexpr int am = AJ % NM, ar = AJ / NM, an = (kWsA - 1 - am) / NM + 1;
@@ -217,13 +240,17 @@ __device__ __forceinline__ void ws_acc_slot(const float *__restrict__ recs, cons
                 const float *__restrict__ hd = hbase + (size_t)T0 * 2 * kHand;
                 const float *__restrict__ rc = recs + ((size_t)T0 * kWsRing + (tag - 1)) * kRec;
                 if constexpr (mine) {
+                    // dW_m += delta_{m+1} (x) h_m in the row-block order of the forward's weights: register pair (16 w + n, 16 (w + 1)
+                    // + n) of lane (r, i) is dW[16 w + i][16 r + ((i - n) & 15)], so rotation n of h_m (natural layout, the DPP
+                    // operand) is shared by the four accumulators and the multipliers are delta_{m+1} of the units 16 w + i --
+                    // four LDS reads.  One v_mov_b32_dpp + two v_pk_fma_f32 per rotation instead of four v_fmac_f32_dpp.
                     const int p16 = lane & 15;
-                    const float *__restrict__ hr = rc + am * kWave;                       // h_m: the input of matrix m
-                    float Rh[4];
-                    Rh[0] = hr[p16]; Rh[1] = hr[16 + p16]; Rh[2] = hr[32 + p16]; Rh[3] = hr[48 + p16];
-                    const float dm = hd[(am + 1) * kWave + lane];                        // delta_{m+1}
-                    asm volatile("" : "+v"(Rh[0]), "+v"(Rh[1]), "+v"(Rh[2]), "+v"(Rh[3]));
-                    mlp_outer_step<0>(gw, dm, Rh);
+                    const float *__restrict__ dl = hd + (am + 1) * kWave;                  // delta_{m+1}
+                    const float hn = rc[am * kWave + lane];                              // h_m: the input of matrix m
+                    f2_t D01, D23;
+                    D01.x = dl[p16]; D01.y = dl[16 + p16]; D23.x = dl[32 + p16]; D23.y = dl[48 + p16];
+                    const float dm = dl[lane];
+                    ws_outer_blk(gw, D01, D23, hn);
                     gb += dm;                                                            // bias of hidden layer m + 2
                 }
                 if constexpr (edge) {
@@ -253,7 +280,7 @@ __device__ __forceinline__ void ws_acc_slot(const float *__restrict__ recs, cons
 }
 template <int NL, int U, int AJ>
 __device__ __forceinline__ void ws_acc_loop(const float *__restrict__ recs, const float *__restrict__ hands, const int *__restrict__ tags,
-                                            const int n_iter, const bool work, const int lane, float (&gw)[kMaxH], float &gb, float (&ge)[17])
+                                            const int n_iter, const bool work, const int lane, f2_t (&gw)[kMaxH / 2], float &gb, float (&ge)[17])
 {
     constexpr int kHand = ws_hand_elems<NL>();
 #pragma unroll 1
@@ -335,7 +362,7 @@ __global__ __launch_bounds__(64 * kWsWaves) void solve_bwd_ws_kernel(const AdjAr
 
     // ---- the two roles: each has its OWN loop (its registers are live in its branch only: 64 accumulators here, the
     //      propagation state there), both loops execute the same n_iter barriers ---------------------------------------------
-    R gw[kMaxH];                                          // A: dW of one hidden matrix (rotating-operand register order)
+    f2_t gw[kMaxH / 2];                                   // A: dW of one hidden matrix (row-block order, accumulator pairs: ws_acc_slot)
     R gb = 0.f;                                           // A: bias of that matrix's layer
     R ge[17];                                             // A_4..7: W1 (9), b_1, Wout (6), bout
     R go = 0.f;                                           // P: lane p < 17 holds d/d(ode constant p)
@@ -568,7 +595,7 @@ __global__ __launch_bounds__(64 * kWsWaves) void solve_bwd_ws_kernel(const AdjAr
         }
     } else {
 #pragma unroll
-        for (int r = 0; r < kMaxH; ++r) gw[r] = 0.f;
+        for (int r = 0; r < kMaxH / 2; ++r) gw[r] = f2_t{0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < 17; ++i) ge[i] = 0.f;
         // one instantiation per accumulation wave: which slots it serves is a compile-time table, every LDS address below is a
@@ -598,8 +625,11 @@ __global__ __launch_bounds__(64 * kWsWaves) void solve_bwd_ws_kernel(const AdjAr
             if (!isP && ar == rr) {
 #pragma unroll
                 for (int r = 0; r < kMaxH; ++r) {
-                    R *dst = wt + (size_t)am * kMaxH * kMaxH + lane * kMaxH + wcol<R>(r, lane);
-                    *dst = (rr == 0) ? gw[r] : *dst + gw[r];
+                    // accumulator 16 w + n of lane (q, i) is dW[16 w + i][16 q + ((i - n) & 15)]; the pair index is 2 n + (w >> 1)
+                    const int w = r >> 4, n = r & 15, i = lane & 15, q = lane >> 4;
+                    const R v = (w & 1) ? gw[2 * n + (w >> 1)].y : gw[2 * n + (w >> 1)].x;
+                    R *dst = wt + (size_t)am * kMaxH * kMaxH + (16 * w + i) * kMaxH + 16 * q + ((i - n) & 15);
+                    *dst = (rr == 0) ? v : *dst + v;
                 }
             }
             __syncthreads();
