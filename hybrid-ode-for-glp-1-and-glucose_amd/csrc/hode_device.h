@@ -228,14 +228,18 @@ template <typename R> __device__ __forceinline__ void tableau_rowsT_store(R *row
 __device__ __forceinline__ float mlp_hidden(const float (&w)[64], float bias, float h);
 __device__ __forceinline__ double mlp_hidden(const double (&w)[64], double bias, double h);
 __device__ __forceinline__ float mlp_hidden_relu(const float (&w)[64], float bias, float h);
-template <bool RELU> __device__ __forceinline__ float mlp_hidden_blk(const float (&w)[64], float bias, float h);
-template <bool RELU> __device__ __forceinline__ double mlp_hidden_blk(const double (&)[64], double, double) { return 0.0; }
+typedef float f2_t __attribute__((ext_vector_type(2)));       // an even-aligned VGPR pair: operand of the packed fp32 instructions
+template <bool RELU> __device__ __forceinline__ float mlp_hidden_blk(const f2_t (&wp)[32], float bias, float h);
 __device__ __forceinline__ double mlp_hidden_relu(const double (&w)[64], double bias, double h);
 template <typename R, int NL> struct MlpRegs {
     R w1[9];                          // W1[j][0..8]
     R w1g;                            // W1[j][4] + W1[j][7]: the weight of GLP1, which the input row holds twice
     R b[NL];                          // b_l[j]
-    R wh[(NL > 1) ? NL - 1 : 1][kMaxH]; // fp64: W_l[j][0..63], l = 2..NL; fp32: the row-block order of mlp_hidden_blk
+    // fp64: W_l[j][0..63], l = 2..NL.  fp32: the row-block order of mlp_hidden_blk as the register PAIRS its packed FMAs take --
+    // wh[l][2 n] = (w0_n, w1_n), wh[l][2 n + 1] = (w2_n, w3_n) -- filled pair by pair in mlp_load (gathered into single registers first
+    // and paired up afterwards, hipcc shuffled the 192 weights through 456 B of scratch per lane: 240 MB of HBM traffic per launch)
+    using HW = std::conditional_t<sizeof(R) == 4, f2_t, R>;
+    HW wh[(NL > 1) ? NL - 1 : 1][sizeof(R) == 4 ? kMaxH / 2 : kMaxH];
     R w5[6];                          // Wout[o][j]
     R w5r[8];                         // fp32: Wout[lane & 7] in rotating order (out_rot_fill); unused in fp64
     R b5;                             // lane l: bout[l & 7] (0 for slots 6,7)
@@ -339,7 +343,7 @@ __device__ __forceinline__ void mlp_load(MlpRegs<R, NL> &W, const R *__restrict_
         const R *row = p + (size_t)j * H;
         if constexpr (sizeof(R) == 4) {
             // row-block order (mlp_hidden_blk): lane (r, i) = lane 16 r + i keeps, for w = 0..3 and n = 0..15,
-            //     wh[l][16 w + n] = W_l[16 w + i][16 r + ((i - n) & 15)]
+            //     weight (w, n) = W_l[16 w + i][16 r + ((i - n) & 15)]    -> half (w & 1) of the pair wh[l][2 n + (w >> 1)]
             // gathered straight from L2 (192 dword loads per lane and trajectory, ~0.5 % of a 241-point solve)
             (void)stage;
             (void)row;
@@ -351,7 +355,9 @@ __device__ __forceinline__ void mlp_load(MlpRegs<R, NL> &W, const R *__restrict_
                 for (int n = 0; n < 16; ++n) {
                     const int c = 16 * r + ((i - n) & 15);
                     const bool ok = u < H && c < H;
-                    W.wh[l][16 * w + n] = ok ? p[(size_t)(ok ? u : 0) * H + (ok ? c : 0)] : R(0);
+                    const R v = ok ? p[(size_t)(ok ? u : 0) * H + (ok ? c : 0)] : R(0);
+                    if (w & 1) W.wh[l][2 * n + (w >> 1)].y = v;
+                    else W.wh[l][2 * n + (w >> 1)].x = v;
                 }
             }
         } else {
@@ -521,26 +527,23 @@ __device__ __forceinline__ float mlp_hidden_relu(const float (&w)[kMaxH], float 
 // for the 32-bit v_mov_b32_dpp inside one statement; naming a fixed pair such as v[0:1] and declaring it clobbered was tried: hipcc
 // then spills whatever lived there and reloads it -- with a full vmcnt wait -- inside the stage loop of the taping kernel).  The
 // s_nops hipcc puts between the statements are issue slots of the SIMD's other wave and cost nothing measurable.
-typedef float f2_t __attribute__((ext_vector_type(2)));
-template <bool RELU> __device__ __forceinline__ float mlp_hidden_blk(const float (&w)[kMaxH], float bias, float h)
+template <bool RELU> __device__ __forceinline__ float mlp_hidden_blk(const f2_t (&wp)[kMaxH / 2], float bias, float h)
 {
     f2_t a01, a23, hr;
     // n = 0: the lane's own activation (no rotation); plain products start the sums (h is a fresh VALU result: these two
     // instructions are also the wait states its first DPP read needs)
     {
-        const f2_t w01 = {w[0], w[16]}, w23 = {w[32], w[48]};
         f2_t hh;
         hh.x = h;
-        asm("v_pk_mul_f32 %0, %2, %4 op_sel_hi:[1,0]\n\tv_pk_mul_f32 %1, %3, %4 op_sel_hi:[1,0]" : "=&v"(a01), "=&v"(a23) : "v"(w01), "v"(w23), "v"(hh));
+        asm("v_pk_mul_f32 %0, %2, %4 op_sel_hi:[1,0]\n\tv_pk_mul_f32 %1, %3, %4 op_sel_hi:[1,0]" : "=&v"(a01), "=&v"(a23) : "v"(wp[0]), "v"(wp[1]), "v"(hh));
     }
 #define HODE_BK_STEP(n)                                                                                                        \
     {                                                                                                                          \
         float lo;                                                                                                              \
         asm("v_mov_b32_dpp %0, %1 row_ror:" #n " row_mask:0xf bank_mask:0xf" : "=v"(lo) : "v"(h));                             \
         hr.x = lo;                                                                                                             \
-        const f2_t w01 = {w[n], w[16 + n]}, w23 = {w[32 + n], w[48 + n]};                                                      \
         asm("v_pk_fma_f32 %0, %2, %4, %0 op_sel_hi:[1,0,1]\n\tv_pk_fma_f32 %1, %3, %4, %1 op_sel_hi:[1,0,1]"                  \
-            : "+v"(a01), "+v"(a23) : "v"(w01), "v"(w23), "v"(hr));                                                             \
+            : "+v"(a01), "+v"(a23) : "v"(wp[2 * n]), "v"(wp[2 * n + 1]), "v"(hr));                                             \
     }
     HODE_BK_STEP(1) HODE_BK_STEP(2) HODE_BK_STEP(3) HODE_BK_STEP(4) HODE_BK_STEP(5) HODE_BK_STEP(6) HODE_BK_STEP(7) HODE_BK_STEP(8)
     HODE_BK_STEP(9) HODE_BK_STEP(10) HODE_BK_STEP(11) HODE_BK_STEP(12) HODE_BK_STEP(13) HODE_BK_STEP(14) HODE_BK_STEP(15)
