@@ -236,7 +236,7 @@ template <typename R, int NL> struct MlpRegs {
     R w1g;                            // W1[j][4] + W1[j][7]: the weight of GLP1, which the input row holds twice
     R b[NL];                          // b_l[j]
     // fp64: W_l[j][0..63], l = 2..NL.  fp32: the row-block order of mlp_hidden_blk as the register PAIRS its packed FMAs take --
-    // wh[l][2 n] = (w0_n, w1_n), wh[l][2 n + 1] = (w2_n, w3_n) -- filled pair by pair in mlp_load (gathered into single registers first
+    // wh[l][2 n] = (w0_n, w2_n), wh[l][2 n + 1] = (w1_n, w3_n) -- filled pair by pair in mlp_load (gathered into single registers first
     // and paired up afterwards, hipcc shuffled the 192 weights through 456 B of scratch per lane: 240 MB of HBM traffic per launch)
     using HW = std::conditional_t<sizeof(R) == 4, f2_t, R>;
     HW wh[(NL > 1) ? NL - 1 : 1][sizeof(R) == 4 ? kMaxH / 2 : kMaxH];
@@ -343,7 +343,7 @@ __device__ __forceinline__ void mlp_load(MlpRegs<R, NL> &W, const R *__restrict_
         const R *row = p + (size_t)j * H;
         if constexpr (sizeof(R) == 4) {
             // row-block order (mlp_hidden_blk): lane (r, i) = lane 16 r + i keeps, for w = 0..3 and n = 0..15,
-            //     weight (w, n) = W_l[16 w + i][16 r + ((i - n) & 15)]    -> half (w & 1) of the pair wh[l][2 n + (w >> 1)]
+            //     weight (w, n) = W_l[16 w + i][16 r + ((i - n) & 15)]    -> half (w >> 1) of the pair wh[l][2 n + (w & 1)]
             // gathered straight from L2 (192 dword loads per lane and trajectory, ~0.5 % of a 241-point solve)
             (void)stage;
             (void)row;
@@ -356,8 +356,8 @@ __device__ __forceinline__ void mlp_load(MlpRegs<R, NL> &W, const R *__restrict_
                     const int c = 16 * r + ((i - n) & 15);
                     const bool ok = u < H && c < H;
                     const R v = ok ? p[(size_t)(ok ? u : 0) * H + (ok ? c : 0)] : R(0);
-                    if (w & 1) W.wh[l][2 * n + (w >> 1)].y = v;
-                    else W.wh[l][2 * n + (w >> 1)].x = v;
+                    if (w >> 1) W.wh[l][2 * n + (w & 1)].y = v;
+                    else W.wh[l][2 * n + (w & 1)].x = v;
                 }
             }
         } else {
@@ -508,6 +508,32 @@ __device__ __forceinline__ float mlp_hidden_relu(const float (&w)[kMaxH], float 
     HODE_MV_LAYER("\n\tv_max_f32 %[a0], 0, %[a0]")
 }
 #undef HODE_MV_LAYER
+// The four accumulators of a row-block product -- pairs (a0, a2), (a1, a3) -- summed over the four 16-lane rows and transposed
+// (row t <- unit 16 t + i): two v_permlane16_swap, ONE packed add, one v_permlane32_swap, one add (+ bias, + ReLU).
+// (q0 + q1) + (q2 + q3) + b: the order every fp32 kernel of this library uses.  Every swap reads data at least two instructions old.
+template <bool RELU, bool BIAS> __device__ __forceinline__ float blk_rows_finish(f2_t a02, f2_t a13, float bias)
+{
+    asm("s_nop 1\n\t"                          /* (hipcc may have just COPIED an accumulator) */
+        "v_permlane16_swap_b32 %[a2], %[a3]\n\t" /* a2 = [u2.q0 u3.q0 u2.q2 u3.q2]   a3 = [u2.q1 u3.q1 u2.q3 u3.q3] */
+        "s_nop 0\n\t"
+        "v_permlane16_swap_b32 %[a0], %[a1]"      /* a0 = [u0.q0 u1.q0 u0.q2 u1.q2]   a1 = [u0.q1 u1.q1 u0.q3 u1.q3] */
+        : [a0] "+v"(a02.x), [a2] "+v"(a02.y), [a1] "+v"(a13.x), [a3] "+v"(a13.y));
+    asm("s_nop 0\n\tv_pk_add_f32 %0, %0, %1" : "+v"(a02) : "v"(a13));     // rows: u0 / u2 q0+q1, u1 / u3 q0+q1, q2+q3, q2+q3
+    float a0 = a02.x, a2 = a02.y;
+    if constexpr (BIAS) {
+        if constexpr (RELU) {
+            asm("s_nop 1\n\tv_permlane32_swap_b32 %[a0], %[a2]\n\tv_add_f32 %[a0], %[a0], %[a2]\n\tv_add_f32 %[a0], %[a0], %[bias]\n\tv_max_f32 %[a0], 0, %[a0]"
+                : [a0] "+v"(a0), [a2] "+v"(a2) : [bias] "v"(bias));
+        } else {
+            asm("s_nop 1\n\tv_permlane32_swap_b32 %[a0], %[a2]\n\tv_add_f32 %[a0], %[a0], %[a2]\n\tv_add_f32 %[a0], %[a0], %[bias]"
+                : [a0] "+v"(a0), [a2] "+v"(a2) : [bias] "v"(bias));
+        }
+    } else {
+        asm("s_nop 1\n\tv_permlane32_swap_b32 %[a0], %[a2]\n\tv_add_f32 %[a0], %[a0], %[a2]" : [a0] "+v"(a0), [a2] "+v"(a2));
+    }
+    return a0;
+}
+
 // ---- one hidden layer WITHOUT row replication (fp32, register kernel) ---------------------------------------------------------
 // Lane (r, i) = lane 16 r + i keeps w[16 w + n] = W[16 w + i][16 r + ((i - n) & 15)]: accumulator a_w of the lane is the part
 // of unit 16 w + i that comes from the lane's OWN 16-lane row of the activation vector, so h in its natural layout (unit per
@@ -529,13 +555,14 @@ __device__ __forceinline__ float mlp_hidden_relu(const float (&w)[kMaxH], float 
 // s_nops hipcc puts between the statements are issue slots of the SIMD's other wave and cost nothing measurable.
 template <bool RELU> __device__ __forceinline__ float mlp_hidden_blk(const f2_t (&wp)[kMaxH / 2], float bias, float h)
 {
-    f2_t a01, a23, hr;
+    // accumulator pairs (a0, a2) and (a1, a3): after the two 16-lane swaps the sums a0 + a1 and a2 + a3 are ONE packed add
+    f2_t a02, a13, hr;
     // n = 0: the lane's own activation (no rotation); plain products start the sums (h is a fresh VALU result: these two
     // instructions are also the wait states its first DPP read needs)
     {
         f2_t hh;
         hh.x = h;
-        asm("v_pk_mul_f32 %0, %2, %4 op_sel_hi:[1,0]\n\tv_pk_mul_f32 %1, %3, %4 op_sel_hi:[1,0]" : "=&v"(a01), "=&v"(a23) : "v"(wp[0]), "v"(wp[1]), "v"(hh));
+        asm("v_pk_mul_f32 %0, %2, %4 op_sel_hi:[1,0]\n\tv_pk_mul_f32 %1, %3, %4 op_sel_hi:[1,0]" : "=&v"(a02), "=&v"(a13) : "v"(wp[0]), "v"(wp[1]), "v"(hh));
     }
 #define HODE_BK_STEP(n)                                                                                                        \
     {                                                                                                                          \
@@ -543,27 +570,12 @@ template <bool RELU> __device__ __forceinline__ float mlp_hidden_blk(const f2_t 
         asm("v_mov_b32_dpp %0, %1 row_ror:" #n " row_mask:0xf bank_mask:0xf" : "=v"(lo) : "v"(h));                             \
         hr.x = lo;                                                                                                             \
         asm("v_pk_fma_f32 %0, %2, %4, %0 op_sel_hi:[1,0,1]\n\tv_pk_fma_f32 %1, %3, %4, %1 op_sel_hi:[1,0,1]"                  \
-            : "+v"(a01), "+v"(a23) : "v"(wp[2 * n]), "v"(wp[2 * n + 1]), "v"(hr));                                             \
+            : "+v"(a02), "+v"(a13) : "v"(wp[2 * n]), "v"(wp[2 * n + 1]), "v"(hr));                                             \
     }
     HODE_BK_STEP(1) HODE_BK_STEP(2) HODE_BK_STEP(3) HODE_BK_STEP(4) HODE_BK_STEP(5) HODE_BK_STEP(6) HODE_BK_STEP(7) HODE_BK_STEP(8)
     HODE_BK_STEP(9) HODE_BK_STEP(10) HODE_BK_STEP(11) HODE_BK_STEP(12) HODE_BK_STEP(13) HODE_BK_STEP(14) HODE_BK_STEP(15)
 #undef HODE_BK_STEP
-    float a0 = a01.x, a1 = a01.y, a2 = a23.x, a3 = a23.y;
-#define HODE_BK_TAIL(TAIL)                                                                                                    \
-    asm("s_nop 1\n\t"                         /* (hipcc may have just COPIED an accumulator: a swap reads two-instruction-old data) */ \
-        "v_permlane16_swap_b32 %[a2], %[a3]\n\t" /* a2 = [u2.q0 u3.q0 u2.q2 u3.q2]   a3 = [u2.q1 u3.q1 u2.q3 u3.q3] */         \
-        "s_nop 0\n\t"                                                                                                         \
-        "v_permlane16_swap_b32 %[a0], %[a1]\n\t" /* a0 = [u0.q0 u1.q0 u0.q2 u1.q2]   a1 = [u0.q1 u1.q1 u0.q3 u1.q3] */         \
-        "v_add_f32 %[a2], %[a2], %[a3]\n\t"      /* rows: u2 q0+q1, u3 q0+q1, u2 q2+q3, u3 q2+q3 */                            \
-        "v_add_f32 %[a0], %[a0], %[a1]\n\t"      /*       u0 q0+q1, u1 q0+q1, u0 q2+q3, u1 q2+q3 */                            \
-        "s_nop 1\n\t"                                                                                                         \
-        "v_permlane32_swap_b32 %[a0], %[a2]\n\t" /* a0 = q0+q1 of u0 u1 u2 u3, a2 = q2+q3 of u0 u1 u2 u3 (u_t in row t) */     \
-        "v_add_f32 %[a0], %[a0], %[a2]\n\t"                                                                                   \
-        "v_add_f32 %[a0], %[a0], %[bias]" TAIL                                                                                \
-        : [a0] "+v"(a0), [a1] "+v"(a1), [a2] "+v"(a2), [a3] "+v"(a3) : [bias] "v"(bias));
-    if constexpr (RELU) { HODE_BK_TAIL("\n\tv_max_f32 %[a0], 0, %[a0]") } else { HODE_BK_TAIL("") }
-#undef HODE_BK_TAIL
-    return a0;
+    return blk_rows_finish<RELU, true>(a02, a13, bias);
 }
 // acc[q] += sum_n row_ror:n(R[q]) * w[16 q + n], n ascending within each accumulator; R[] must be two wait states old
 __device__ __forceinline__ void rot_matvec64(const float (&w)[kMaxH], const float (&R)[4], float (&acc)[4])

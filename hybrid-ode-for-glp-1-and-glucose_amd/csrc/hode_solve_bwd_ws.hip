@@ -94,7 +94,7 @@ __device__ __forceinline__ void wt_blk_store(float *__restrict__ wt, const float
     const float *Wl = nn_p + 9 * H + H;
     for (int l = 0; l < NLm1; ++l) {
         for (int e = tid; e < kMaxH * kMaxH; e += nthreads) {
-            const int w = e & 3, lane = (e >> 2) & 63, n = e >> 8;
+            const int w = ((e & 1) << 1) | ((e >> 1) & 1), lane = (e >> 2) & 63, n = e >> 8;      // word = { w0, w2, w1, w3 }: the pairs (a0, a2), (a1, a3)
             const int i = lane & 15, r = lane >> 4;
             const int row = 16 * r + ((i - n) & 15), col = 16 * w + i;
             wt[(size_t)l * kMaxH * kMaxH + e] = (row < H && col < H) ? Wl[(size_t)row * H + col] : 0.f;
@@ -133,22 +133,8 @@ template <int G> __device__ __forceinline__ void ws_wt_group(const Vec4<float> (
     }
 #undef HODE_WS_STEP
 }
-// the four accumulators -> (W^T delta)[unit of the lane]: sum over the four 16-lane rows and transpose (row t <- unit 16 t + i)
-__device__ __forceinline__ float ws_wt_finish(const f2_t a01, const f2_t a23)
-{
-    float a0 = a01.x, a1 = a01.y, a2 = a23.x, a3 = a23.y;
-    asm("s_nop 1\n\t"
-        "v_permlane16_swap_b32 %[a2], %[a3]\n\t"
-        "s_nop 0\n\t"
-        "v_permlane16_swap_b32 %[a0], %[a1]\n\t"
-        "v_add_f32 %[a2], %[a2], %[a3]\n\t"
-        "v_add_f32 %[a0], %[a0], %[a1]\n\t"
-        "s_nop 1\n\t"
-        "v_permlane32_swap_b32 %[a0], %[a2]\n\t"
-        "v_add_f32 %[a0], %[a0], %[a2]"
-        : [a0] "+v"(a0), [a1] "+v"(a1), [a2] "+v"(a2), [a3] "+v"(a3));
-    return a0;
-}
+// the four accumulators -> (W^T delta)[unit of the lane]: hode_device.h blk_rows_finish (pairs (a0, a2), (a1, a3); no bias)
+__device__ __forceinline__ float ws_wt_finish(const f2_t a02, const f2_t a13) { return blk_rows_finish<false, false>(a02, a13, 0.f); }
 // The sixteen 16-byte reads of a matrix are issued ahead of their use: on entry w0 / w1 hold the words of groups 0 and 1 (loaded
 // while the PREVIOUS matrix -- or, for the first matrix of a stage, the previous iteration's tail -- was being worked on), groups
 // 2 and 3 follow into the buffer the group before them has freed, and on exit w0 / w1 hold groups 0 and 1 of `wt_next`: the
@@ -240,7 +226,7 @@ __device__ __forceinline__ void ws_acc_slot(const float *__restrict__ recs, cons
                 const float *__restrict__ hd = hbase + (size_t)T0 * 2 * kHand;
                 const float *__restrict__ rc = recs + ((size_t)T0 * kWsRing + (tag - 1)) * kRec;
                 if constexpr (mine) {
-                    // dW_m += delta_{m+1} (x) h_m in the row-block order of the forward's weights: register pair (16 w + n, 16 (w + 1)
+                    // dW_m += delta_{m+1} (x) h_m in the row-block order of the forward's weights: register pair (16 w + n, 16 (w + 2)
                     // + n) of lane (r, i) is dW[16 w + i][16 r + ((i - n) & 15)], so rotation n of h_m (natural layout, the DPP
                     // operand) is shared by the four accumulators and the multipliers are delta_{m+1} of the units 16 w + i --
                     // four LDS reads.  One v_mov_b32_dpp + two v_pk_fma_f32 per rotation instead of four v_fmac_f32_dpp.
@@ -248,7 +234,7 @@ __device__ __forceinline__ void ws_acc_slot(const float *__restrict__ recs, cons
                     const float *__restrict__ dl = hd + (am + 1) * kWave;                  // delta_{m+1}
                     const float hn = rc[am * kWave + lane];                              // h_m: the input of matrix m
                     f2_t D01, D23;
-                    D01.x = dl[p16]; D01.y = dl[16 + p16]; D23.x = dl[32 + p16]; D23.y = dl[48 + p16];
+                    D01.x = dl[p16]; D01.y = dl[32 + p16]; D23.x = dl[16 + p16]; D23.y = dl[48 + p16];     // pairs (w0, w2), (w1, w3)
                     const float dm = dl[lane];
                     ws_outer_blk(gw, D01, D23, hn);
                     gb += dm;                                                            // bias of hidden layer m + 2
@@ -625,9 +611,9 @@ __global__ __launch_bounds__(64 * kWsWaves) void solve_bwd_ws_kernel(const AdjAr
             if (!isP && ar == rr) {
 #pragma unroll
                 for (int r = 0; r < kMaxH; ++r) {
-                    // accumulator 16 w + n of lane (q, i) is dW[16 w + i][16 q + ((i - n) & 15)]; the pair index is 2 n + (w >> 1)
+                    // accumulator 16 w + n of lane (q, i) is dW[16 w + i][16 q + ((i - n) & 15)]; it is half (w >> 1) of the pair 2 n + (w & 1)
                     const int w = r >> 4, n = r & 15, i = lane & 15, q = lane >> 4;
-                    const R v = (w & 1) ? gw[2 * n + (w >> 1)].y : gw[2 * n + (w >> 1)].x;
+                    const R v = (w >> 1) ? gw[2 * n + (w & 1)].y : gw[2 * n + (w & 1)].x;
                     R *dst = wt + (size_t)am * kMaxH * kMaxH + (16 * w + i) * kMaxH + 16 * q + ((i - n) & 15);
                     *dst = (rr == 0) ? v : *dst + v;
                 }
