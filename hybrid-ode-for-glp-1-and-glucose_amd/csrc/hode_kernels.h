@@ -12,7 +12,7 @@ template <typename R> struct SolveArgs {
     R rtol, atol;
     R *y;
     int32_t *status, *nsteps, *nfev;
-    R *tape;            // [B][max_steps][8] = {t, h, y0..y5}
+    R *tape;            // [B][max_steps][8] = {t, h, t0, 1/(t1-t0), v0, v1-v0, d0, d1-d0}: the step + the constants of its grid interval
     int32_t *tape_seg;  // [B][max_steps] grid interval of each accepted step (| kSegClosed)
     R *tape_stage;      // [B][max_steps][6 stages][tape_slot_elems]: layer activations + stage state of every accepted step
     int L;              // hidden layers (plain count)

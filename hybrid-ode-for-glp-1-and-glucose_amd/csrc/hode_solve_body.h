@@ -152,13 +152,16 @@ __device__ __forceinline__ void solve_one(const SolveArgs<R> &a, const int b, co
         // which grid rows a FAILED trajectory still wrote)
         auto tape_put = [&](R tc, R h, bool closes) {
             if constexpr (TAPE) {
-                // entry = {t, h, y0..y5}: lanes 0..5 store the state, lanes 6,7 store t and h
-                const R e = (lane < 6) ? Y : (lane == 6) ? tc : h;
+                // entry = {t, h, t0, 1 / (t1 - t0), v0, v1 - v0, d0, d1 - d0}: the step and the constants of its grid interval as THIS
+                // kernel used them -- all the adjoint's step header needs, in one 32-byte record it can fetch without knowing the
+                // interval index first (rounds 1-3 stored the state y0..y5 in slots 2..7; no adjoint kernel ever read it)
                 // (the lane's slot is laundered: hipcc otherwise keeps the per-lane pointer tape + slot live across the whole
                 //  integration -- two VGPRs the kernel does not have: it was spilled and reloaded from scratch every step)
-                int slot_l = (lane < 6) ? lane + 2 : lane - 6;
+                int slot_l = lane;
                 asm volatile("" : "+v"(slot_l));
-                if (lane < 8) tape[(size_t)ns * 8 + slot_l] = e;
+                const R e = (slot_l == 0) ? tc : (slot_l == 1) ? h : (slot_l == 2) ? t0 : (slot_l == 3) ? inv_len : (slot_l == 4) ? v0
+                          : (slot_l == 5) ? dv : (slot_l == 6) ? (use_gd ? d0 : R(0)) : (use_gd ? dd : R(0));   // (no GD input: both are zero anyway)
+                if (slot_l < 8) tape[(size_t)ns * 8 + slot_l] = e;
                 if (lane == 0) tseg[ns] = k | (closes ? kSegClosed : 0);
             }
         };

@@ -40,18 +40,26 @@ constexpr int kWsP = 8;                                    // propagation waves 
 constexpr int kWsA = 8;                                    // accumulation waves per workgroup
 constexpr int kWsWaves = kWsP + kWsA;
 constexpr int kWsRing = 3;                                 // record ring: being DMA'd | being propagated | being accumulated
+#ifdef HODE_LAB
+// lab library only (HODE_WS_DBG bit 1024): shader-clock stamps of workgroup (0, 0) over 32 iterations, [iteration][wave][point]
+constexpr int kWsTraceIt0 = 200, kWsTraceIts = 32, kWsTracePts = 10;
+__device__ unsigned long long g_ws_trace[kWsTraceIts * kWsWaves * kWsTracePts];
+#define WS_STAMP(i) if (trace_on) tstamp[i] = __builtin_amdgcn_s_memtime()
+#define WS_TRACE_DECL unsigned long long tstamp[kWsTracePts] = {}; const bool trace_wg = (dbg & 1024) && blockIdx.x == 0 && blockIdx.y == 0; bool trace_on = false
+#define WS_TRACE_BEGIN(it) trace_on = trace_wg && (it) >= kWsTraceIt0 && (it) < kWsTraceIt0 + kWsTraceIts
+#define WS_TRACE_FLUSH(it, wave) if (trace_on && lane == 0) { _Pragma("unroll") for (int i_ = 0; i_ < kWsTracePts; ++i_) g_ws_trace[(((it) - kWsTraceIt0) * kWsWaves + (wave)) * kWsTracePts + i_] = tstamp[i_]; }
+#else
+#define WS_STAMP(i)
+#define WS_TRACE_DECL
+#define WS_TRACE_BEGIN(it)
+#define WS_TRACE_FLUSH(it, wave)
+#endif
 template <int NL> constexpr int ws_rec_elems() { return (NL + 1) * kWave; }          // NL rows + the stage state (8 of 64 used)
 template <int NL> constexpr int ws_hand_elems() { return (NL + 1) * kWave; }         // delta_1..delta_NL + {kb[6], t, tvns} x 8
 template <int NL, int U> constexpr size_t ws_lds_elems()
 {
     return (size_t)(NL - 1) * kMaxH * kMaxH + 8 * kWave + (size_t)kWsP * U * kWsRing * ws_rec_elems<NL>() +
-           (size_t)kWsP * U * 2 * ws_hand_elems<NL>() + 2 * 16 + 16;
-}
-
-__device__ __forceinline__ float inp_at_w(const float *__restrict__ p, int mode, int b, int T, int k)
-{
-    if (mode == 0) return 0.f;
-    return (mode == 1) ? p[b] : p[(size_t)b * T + k];
+           (size_t)kWsP * U * 2 * ws_hand_elems<NL>() + 2 * 16 + 16 + (size_t)kWsP * U * 2 * kWave;
 }
 
 // J_mech^T kb as mech_vjp (hode_device.h) computes it, with the five terms evaluated on ALL lanes and selected by lane -- the
@@ -185,32 +193,44 @@ __device__ __forceinline__ void ws_wt_mul(const float *__restrict__ wt, const fl
 
 }  // namespace
 
-// gw[2 n], gw[2 n + 1] += (D01, D23) * row_ror:n(hn): the sixteen rotations of one outer-product update (see ws_acc_slot)
-__device__ __forceinline__ void ws_outer_blk(f2_t (&gw)[kMaxH / 2], const f2_t D01, const f2_t D23, const float hn)
+// gw[2 c], gw[2 c + 1] += (D01, D23) * h[16 r + c], c = 0..15: the sixteen columns of one outer-product update (see ws_acc_slot).
+// The lane's 16-lane row of h arrives as four 16-byte LDS reads (q[0..3]: the sixteen lanes of a row read the same 64 bytes --
+// a broadcast, conflict-free); each packed FMA takes the low or the high half of one of the loaded register pairs (op_sel), so no
+// cross-lane move is left on the vector pipe: 32 v_pk_fma_f32 per update where round 3 issued 15 v_mov_b32_dpp + 32
+// (tools/ubench/lb_ubench.hip: 107 against 153 SIMD cycles per update at four waves per SIMD).
+__device__ __forceinline__ void ws_outer_nat(f2_t (&gw)[kMaxH / 2], const f2_t D01, const f2_t D23, const Vec4<float> (&q)[4])
 {
-    {
-        f2_t hh;
-        hh.x = hn;
-        asm("v_pk_fma_f32 %0, %2, %4, %0 op_sel_hi:[1,0,1]\n\tv_pk_fma_f32 %1, %3, %4, %1 op_sel_hi:[1,0,1]"
-            : "+v"(gw[0]), "+v"(gw[1]) : "v"(D01), "v"(D23), "v"(hh));
-    }
-#define HODE_WS_OSTEP(N)                                                                                                        \
+#define HODE_WS_OPAIR(K, J)                                                                                                    \
     {                                                                                                                           \
-        float lo;                                                                                                               \
-        asm("v_mov_b32_dpp %0, %1 row_ror:" #N " row_mask:0xf bank_mask:0xf" : "=v"(lo) : "v"(hn));                             \
-        f2_t hr;                                                                                                                \
-        hr.x = lo;                                                                                                              \
+        const f2_t hp = {q[K].v[2 * J], q[K].v[2 * J + 1]};                                                                     \
         asm("v_pk_fma_f32 %0, %2, %4, %0 op_sel_hi:[1,0,1]\n\tv_pk_fma_f32 %1, %3, %4, %1 op_sel_hi:[1,0,1]"                   \
-            : "+v"(gw[2 * N]), "+v"(gw[2 * N + 1]) : "v"(D01), "v"(D23), "v"(hr));                                              \
+            : "+v"(gw[2 * (4 * K + 2 * J)]), "+v"(gw[2 * (4 * K + 2 * J) + 1]) : "v"(D01), "v"(D23), "v"(hp));                   \
+        asm("v_pk_fma_f32 %0, %2, %4, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\tv_pk_fma_f32 %1, %3, %4, %1 op_sel:[0,1,0] op_sel_hi:[1,1,1]" \
+            : "+v"(gw[2 * (4 * K + 2 * J + 1)]), "+v"(gw[2 * (4 * K + 2 * J + 1) + 1]) : "v"(D01), "v"(D23), "v"(hp));           \
     }
-    HODE_WS_OSTEP(1) HODE_WS_OSTEP(2) HODE_WS_OSTEP(3) HODE_WS_OSTEP(4) HODE_WS_OSTEP(5) HODE_WS_OSTEP(6) HODE_WS_OSTEP(7) HODE_WS_OSTEP(8)
-    HODE_WS_OSTEP(9) HODE_WS_OSTEP(10) HODE_WS_OSTEP(11) HODE_WS_OSTEP(12) HODE_WS_OSTEP(13) HODE_WS_OSTEP(14) HODE_WS_OSTEP(15)
-#undef HODE_WS_OSTEP
+    HODE_WS_OPAIR(0, 0) HODE_WS_OPAIR(0, 1) HODE_WS_OPAIR(1, 0) HODE_WS_OPAIR(1, 1)
+    HODE_WS_OPAIR(2, 0) HODE_WS_OPAIR(2, 1) HODE_WS_OPAIR(3, 0) HODE_WS_OPAIR(3, 1)
+#undef HODE_WS_OPAIR
 }
 
+// which accumulation wave keeps the first / last layer gradients of trajectory slot t: the waves of the hidden matrices that have
+// THREE waves (five or six slots each) share the sixteen slots 2 / 2 / 3 / 3 / 3 / 3, the two waves of the last matrix (eight slots
+// each) none -- round 3 gave four slots each to waves 4..7, and wave 5 (eight matrix slots + four edge slots) closed every iteration
+// 3 000 cycles behind the lightest wave (tools/ws_trace.py)
+__host__ __device__ constexpr int ws_edge_owner(int t)
+{
+    constexpr int tab[16] = {0, 1, 3, 4, 6, 7, 3, 4, 6, 7, 3, 4, 6, 7, 0, 1};
+    return tab[t & 15];
+}
+__host__ __device__ constexpr bool ws_has_edges(int aj) { return aj != 2 && aj != 5; }
+
 // Accumulation wave AJ: matrix AJ % (NL-1), rank AJ / (NL-1) among that matrix's waves; slot t belongs to the wave of rank
-// t % (waves of the matrix); waves 4..7 also keep the first / last layer gradients of the slots t with t % 4 == AJ - 4.
+// t % (waves of the matrix); the first / last layer gradients of slot t are kept by wave ws_edge_owner(t).
 // One slot (compile-time t: every LDS address is a base register + an immediate), then the next one.
+// NL = 4 (three hidden matrices): ws_edge_owner; fewer matrices: every matrix has at least four waves of at most four slots, the old
+// deal (waves 4..7, a quarter of the slots each) is balanced
+template <int NL> __host__ __device__ constexpr int edge_of(int t) { return NL == 4 ? ws_edge_owner(t) : 4 + (t & 3); }
+template <int NL> __host__ __device__ constexpr bool has_edges(int aj) { return NL == 4 ? ws_has_edges(aj) : aj >= 4; }
 template <int NL, int U, int AJ, int T0>
 __device__ __forceinline__ void ws_acc_slot(const float *__restrict__ recs, const float *__restrict__ hbase, const int mytag, const int lane,
                                             f2_t (&gw)[kMaxH / 2], float &gb, float (&ge)[17])
@@ -219,24 +239,25 @@ __device__ __forceinline__ void ws_acc_slot(const float *__restrict__ recs, cons
     constexpr int am = AJ % NM, ar = AJ / NM, an = (kWsA - 1 - am) / NM + 1;
     constexpr int kRec = ws_rec_elems<NL>(), kHand = ws_hand_elems<NL>();
     if constexpr (T0 < NT) {
-        constexpr bool mine = (T0 % an) == ar, edge = AJ >= 4 && (T0 & 3) == AJ - 4;
+        constexpr bool mine = (T0 % an) == ar, edge = edge_of<NL>(T0) == AJ;
         if constexpr (mine || edge) {
             const int tag = __builtin_amdgcn_readlane(mytag, T0);
             if (tag != 0) {
                 const float *__restrict__ hd = hbase + (size_t)T0 * 2 * kHand;
                 const float *__restrict__ rc = recs + ((size_t)T0 * kWsRing + (tag - 1)) * kRec;
                 if constexpr (mine) {
-                    // dW_m += delta_{m+1} (x) h_m in the row-block order of the forward's weights: register pair (16 w + n, 16 (w + 2)
-                    // + n) of lane (r, i) is dW[16 w + i][16 r + ((i - n) & 15)], so rotation n of h_m (natural layout, the DPP
-                    // operand) is shared by the four accumulators and the multipliers are delta_{m+1} of the units 16 w + i --
-                    // four LDS reads.  One v_mov_b32_dpp + two v_pk_fma_f32 per rotation instead of four v_fmac_f32_dpp.
+                    // dW_m += delta_{m+1} (x) h_m: register pair (16 w + c, 16 (w + 2) + c) of lane (r, i) is dW[16 w + i][16 r + c] and
+                    // dW[16 (w + 2) + i][16 r + c] -- the four accumulators of a column share h_m[16 r + c], which every lane of row r
+                    // reads from the slot's record (ws_outer_nat), and the multipliers are delta_{m+1} of the units 16 w + i: four
+                    // more LDS reads.  32 v_pk_fma_f32 and no cross-lane instruction.
                     const int p16 = lane & 15;
                     const float *__restrict__ dl = hd + (am + 1) * kWave;                  // delta_{m+1}
-                    const float hn = rc[am * kWave + lane];                              // h_m: the input of matrix m
+                    const Vec4<float> *__restrict__ hrow = reinterpret_cast<const Vec4<float> *>(rc + am * kWave + (lane & 48));   // h_m, the lane's row
+                    const Vec4<float> q[4] = {hrow[0], hrow[1], hrow[2], hrow[3]};
                     f2_t D01, D23;
                     D01.x = dl[p16]; D01.y = dl[32 + p16]; D23.x = dl[16 + p16]; D23.y = dl[48 + p16];     // pairs (w0, w2), (w1, w3)
                     const float dm = dl[lane];
-                    ws_outer_blk(gw, D01, D23, hn);
+                    ws_outer_nat(gw, D01, D23, q);
                     gb += dm;                                                            // bias of hidden layer m + 2
                 }
                 if constexpr (edge) {
@@ -266,17 +287,25 @@ __device__ __forceinline__ void ws_acc_slot(const float *__restrict__ recs, cons
 }
 template <int NL, int U, int AJ>
 __device__ __forceinline__ void ws_acc_loop(const float *__restrict__ recs, const float *__restrict__ hands, const int *__restrict__ tags,
-                                            const int n_iter, const bool work, const int lane, f2_t (&gw)[kMaxH / 2], float &gb, float (&ge)[17])
+                                            const int n_iter, const bool work, const int lane, f2_t (&gw)[kMaxH / 2], float &gb, float (&ge)[17],
+                                            const int dbg)
 {
     constexpr int kHand = ws_hand_elems<NL>();
+    (void)dbg;
+    WS_TRACE_DECL;
 #pragma unroll 1
     for (int it = 0; it < n_iter; ++it) {
+        WS_TRACE_BEGIN(it);
+        WS_STAMP(0);
         if (it > 0 && work) {
             const int rp = (it - 1) & 1;                       // what the propagation waves published one iteration ago
             const int mytag = tags[rp * 16 + (lane & 15)];    // all sixteen tags in one read
             ws_acc_slot<NL, U, AJ, 0>(recs, hands + rp * kHand, mytag, lane, gw, gb, ge);
         }
+        WS_STAMP(8);
         __syncthreads();
+        WS_STAMP(9);
+        WS_TRACE_FLUSH(it, kWsP + AJ);
     }
 }
 
@@ -300,6 +329,16 @@ __global__ __launch_bounds__(64 * kWsWaves) void solve_bwd_ws_kernel(const AdjAr
     R *hands = recs + (size_t)NT * kWsRing * kRec;        // [NT][2][kHand]
     int *tags = reinterpret_cast<int *>(hands + (size_t)NT * 2 * kHand);      // [2][16]: 0 = nothing published, else 1 + ring slot
     int *niter = tags + 2 * 16;
+    // step headers, [NT][2][64]: everything a slot's step needs from global memory besides its stage records, gathered by ONE LDS-DMA
+    // with per-lane addresses one step ahead (two buffers: the current step's constants are read until its last stage):
+    //   words 0..7    the step's tape entry {t, h, t0, 1 / (t1 - t0), v0, v1 - v0, d0, d1 - d0} as the forward wrote it (tape_put)
+    //   words 8 j + c dLoss/dy[b, kn + 1 - j, c], j = 1..6, c < 6: the grid rows the step can close (kn = the interval of the step
+    //                 walked before it, T - 1 for the first)
+    //   words 56..63  the step's interval word
+    // Rounds 1-3 read all of it with scalar / vector loads in the header itself -- interval index first, then the rows behind it: two
+    // dependent HBM round trips, 4 000-6 000 cycles in every sixth iteration with all sixteen waves of the workgroup waiting at the
+    // barrier (tools/ws_trace.py) -- and kept the step constants in twelve VGPRs that pushed the loop into scratch.
+    R *hdrs = reinterpret_cast<R *>(niter + 16);
 
     const int lane = threadIdx.x & 63;
     const int c8 = lane & 7, grp = lane >> 3;
@@ -320,7 +359,7 @@ __global__ __launch_bounds__(64 * kWsWaves) void solve_bwd_ws_kernel(const AdjAr
     // restrict-qualified views: wave-uniform reads of them are scalar loads (through the struct members hipcc has to assume
     // they alias the gx0 stores and falls back to exec-masked vector loads with a full vmcnt wait each)
     const R *__restrict__ const gy_ = a.gy, *__restrict__ const tgrid_ = a.t, *__restrict__ const tape_ = a.tape,
-                        *__restrict__ const tvns_ = a.tvns, *__restrict__ const gd_ = a.gd, *__restrict__ const stage_ = a.tape_stage;
+                        *__restrict__ const stage_ = a.tape_stage;
     const int *__restrict__ const seg_ = a.tape_seg, *__restrict__ const nsteps_ = a.nsteps, *__restrict__ const status_ = a.status;
 
     wt_blk_store(wt, nn_set, a.H, NM, threadIdx.x, 64 * kWsWaves);
@@ -360,7 +399,8 @@ __global__ __launch_bounds__(64 * kWsWaves) void solve_bwd_ws_kernel(const AdjAr
         // edge weights in registers (no accumulators here: there is room); per trajectory: step / stage cursors
         R w1r[8], w5[6];
         OdeP<R> o;
-        R lam[U], ZZ[U], tc[U], h[U], t0[U], inv_len[U], v0[U], dv[U], d0[U], dd[U];
+        R lam[U], ZZ[U];
+        int hp[U];                                        // which of the slot's two header buffers holds the CURRENT step
         int bi_next[U], b[U], n[U], st[U], s[U], knext[U], k[U], cur[U];
         bool active[U], ok[U];
         const R *__restrict__ stg[U];
@@ -393,6 +433,24 @@ __global__ __launch_bounds__(64 * kWsWaves) void solve_bwd_ws_kernel(const AdjAr
         }
         auto rec_of = [&](int u) -> R * { return recs + (size_t)(wave * U + u) * kWsRing * kRec; };
         auto hand_of = [&](int u, int par) -> R * { return hands + ((size_t)(wave * U + u) * 2 + par) * kHand; };
+        auto hdr_of = [&](int u, int par) -> R * { return hdrs + ((size_t)(wave * U + u) * 2 + par) * kWave; };
+        // the header of step `stn` of trajectory b[u] -> buffer `par` (see hdrs above); `kn`: the rows it can close end at kn
+        auto hdr_dma = [&](int u, int stn, int kn, int par) {
+            // three wave-uniform bases, pinned to the scalar unit at the point of use (left to itself hipcc keeps per-lane copies of the
+            // three array pointers live across the whole loop -- six VGPRs it does not have: scratch, with a reload and a full vmcnt
+            // wait behind the record DMA in front of every gather)
+            uint64_t bg = reinterpret_cast<uint64_t>(gy_ + (size_t)b[u] * T * 6);
+            uint64_t bt = reinterpret_cast<uint64_t>(tape_ + ((size_t)b[u] * a.max_steps + stn) * 8);
+            uint64_t bs = reinterpret_cast<uint64_t>(seg_ + (size_t)b[u] * a.max_steps + stn);
+            asm volatile("" : "+s"(bg), "+s"(bt), "+s"(bs));
+            int row = kn + 1 - grp;
+            row = row < 0 ? 0 : row;
+            row = row > T - 1 ? T - 1 : row;
+            const uint32_t off = (grp == 0) ? 4u * c8 : (grp == 7) ? 0u : 4u * (uint32_t)(row * 6 + (c8 < 6 ? c8 : 5));
+            const uint64_t base = (grp == 0) ? bt : (grp == 7) ? bs : bg;
+            const R *p = reinterpret_cast<const R *>(base + off);
+            __builtin_amdgcn_global_load_lds(p, (__attribute__((address_space(3))) void *)hdr_of(u, par), 4, 0, 0);
+        };
         // one record = NL rows of 64 reals + the stage state: NL + 1 DMA instructions off ONE address pair, the row offset is the
         // instruction's immediate (it advances the global and the LDS address alike).  The last row is loaded whole although
         // only 8 reals of it belong to the record: the other 56 are the head of the next record (or, behind the very last one,
@@ -434,6 +492,7 @@ __global__ __launch_bounds__(64 * kWsWaves) void solve_bwd_ws_kernel(const AdjAr
                     st[u] = n[u] - 1;
                     s[u] = S - 1;
                     rec_dma(stg[u] + ((size_t)st[u] * 6 + s[u]) * kSlot, rec_of(u) + cur[u] * kRec);      // its first record
+                    hdr_dma(u, st[u], T - 1, hp[u]);
                     active[u] = true;
                     return;
                 }
@@ -446,51 +505,52 @@ __global__ __launch_bounds__(64 * kWsWaves) void solve_bwd_ws_kernel(const AdjAr
         for (int u = 0; u < U; ++u) {
             bi_next[u] = (wave * U + u) * gridDim.x + blockIdx.x;
             cur[u] = 0; st[u] = -1; s[u] = 0; k[u] = 0; n[u] = 0; b[u] = 0; knext[u] = 0; ok[u] = true;
-            lam[u] = ZZ[u] = tc[u] = h[u] = t0[u] = inv_len[u] = v0[u] = dv[u] = d0[u] = dd[u] = 0.f;
+            lam[u] = ZZ[u] = 0.f;
+            hp[u] = 0;
+            hdr_of(u, 0)[lane] = 0.f;
+            hdr_of(u, 1)[lane] = 0.f;
             stg[u] = stage_;
             start_next(u);
         }
+        WS_TRACE_DECL;
 #pragma unroll 1
         for (int it = 0; it < n_iter; ++it) {
             const int par = it & 1;
-            // ---- step headers: cotangents of the grid rows a step produced, step and interval constants
+            WS_TRACE_BEGIN(it);
+            WS_STAMP(0);
+            // the records to process now and the headers were DMA'd one iteration ago (or at the start of their trajectory)
+            WS_STAMP(1);
+            __builtin_amdgcn_s_waitcnt(0x0f70);                // vmcnt(0)
+            WS_STAMP(2);
+            __builtin_amdgcn_wave_barrier();
+            // ---- step headers: cotangents of the grid rows the step produced, rows k + 1 .. knext; row knext + 1 - j sits in words
+            //      8 j .. 8 j + 5 of the header (j = 1..6).  One row (the usual case) is added as it is, several are summed first
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 if (active[u] && s[u] == S - 1) {
-                    const R *__restrict__ tg = tgrid_ + (a.t_batched ? (size_t)b[u] * T : 0);
-                    const R *__restrict__ tape = tape_ + (size_t)b[u] * a.max_steps * 8;
-                    const int kraw = seg_[(size_t)b[u] * a.max_steps + st[u]];
+                    const R *__restrict__ hh = hdr_of(u, hp[u]);
+                    const int kraw = first_lane(f2i(hh[56]));
                     k[u] = kraw & (kSegClosed - 1);
-                    int hi = knext[u];
-                    if (st[u] == n[u] - 1) {
-                        hi = T - 1;
-                        if (!ok[u]) {              // the last step of a FAILED trajectory: see solve_bwd_kernel
-                            hi = k[u];
-                            if (kraw & kSegClosed) {
-                                hi = k[u] + 1;
-                                while (hi + 1 < T && !(tg[hi + 1] > tg[hi])) ++hi;
-                            }
+                    if (st[u] == n[u] - 1 && !ok[u]) {
+                        // the last step of a FAILED trajectory (the first of the walk): see solve_bwd_kernel
+                        const R *__restrict__ tg = tgrid_ + (a.t_batched ? (size_t)b[u] * T : 0);
+                        int hi = k[u];
+                        if (kraw & kSegClosed) {
+                            hi = k[u] + 1;
+                            while (hi + 1 < T && !(tg[hi + 1] > tg[hi])) ++hi;
                         }
+                        for (int r = k[u] + 1; r <= hi; ++r) inject(u, r);
+                    } else {
+                        const int nrow = knext[u] - k[u];
+                        const R hv = hh[lane];
+                        const R v = (grp >= 1 && grp <= nrow && grp < 7 && c8 < 6) ? hv : 0.f;
+                        lam[u] += group_sum8(v);
+                        for (int r = k[u] + 1; r <= knext[u] - 6; ++r) inject(u, r);      // (more than six rows behind one step: repeated grid times)
                     }
-                    for (int r = k[u] + 1; r <= hi; ++r) inject(u, r);
                     knext[u] = k[u];
-                    tc[u] = tape[(size_t)st[u] * 8 + 0];
-                    h[u] = tape[(size_t)st[u] * 8 + 1];
-                    t0[u] = tg[k[u]];
-                    const R t1 = tg[k[u] + 1];
-                    v0[u] = inp_at_w(tvns_, a.tvns_mode, b[u], T, k[u]);
-                    const R v1 = inp_at_w(tvns_, a.tvns_mode, b[u], T, k[u] + 1);
-                    d0[u] = inp_at_w(gd_, a.gd_mode, b[u], T, k[u]);
-                    const R d1 = inp_at_w(gd_, a.gd_mode, b[u], T, k[u] + 1);
-                    inv_len[u] = first_lane(1.f / (t1 - t0[u]));
-                    dv[u] = first_lane(v1 - v0[u]);
-                    dd[u] = first_lane(d1 - d0[u]);
                     ZZ[u] = 0.f;
                 }
             }
-            // the records to process now were DMA'd one iteration ago (or at the start of their trajectory)
-            __builtin_amdgcn_s_waitcnt(0x0f70);                // vmcnt(0)
-            __builtin_amdgcn_wave_barrier();
             int slot[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -501,6 +561,8 @@ __global__ __launch_bounds__(64 * kWsWaves) void solve_bwd_ws_kernel(const AdjAr
                     // PREVIOUS iteration (they are done with it: a barrier lies in between)
                     const int ns_ = (s[u] > 0) ? s[u] - 1 : S - 1, nst = (s[u] > 0) ? st[u] : st[u] - 1;
                     if (nst >= 0) rec_dma(stg[u] + ((size_t)nst * 6 + ns_) * kSlot, rec_of(u) + cur[u] * kRec);
+                    // one step ahead: the header of the step below this one, into the slot's other buffer
+                    if (s[u] == S - 1 && st[u] >= 1) hdr_dma(u, st[u] - 1, k[u], hp[u] ^ 1);
                 }
             }
             // ---- J^T kb for all U trajectories in ONE basic block (an idle slot computes on stale data; nothing of it is kept):
@@ -514,13 +576,27 @@ __global__ __launch_bounds__(64 * kWsWaves) void solve_bwd_ws_kernel(const AdjAr
 #pragma unroll
                 for (int l = 0; l < NL; ++l) hact[u][l] = rc[l * kWave + lane];
                 const R Ys = rc[NL * kWave + c8];             // stage state, replicated layout
+                // {t, h, t0, 1 / len}, {v0, dv, d0, dd} of the current step: two broadcast reads of the slot's header.  Written as asm:
+                // hipcc puts an s_waitcnt vmcnt(0) in front of any LDS read it sees that MAY alias a pending LDS-DMA -- here the next
+                // record and the next header, issued a moment ago into OTHER buffers -- and the wave would sit out a whole HBM round
+                // trip (~2 000 cycles per iteration, tools/ws_trace.py).  The second statement is the wait these reads need.
+                Vec4<R> sc0, sc1;
+                {
+                    typedef float f4_t __attribute__((ext_vector_type(4)));
+                    f4_t q0, q1;
+                    const unsigned ha = (unsigned)(size_t)(__attribute__((address_space(3))) R *)hdr_of(u, hp[u]);
+                    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16" : "=&v"(q0), "=&v"(q1) : "v"(ha));
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(q0), "+v"(q1));
+                    sc0 = Vec4<R>{{q0.x, q0.y, q0.z, q0.w}};
+                    sc1 = Vec4<R>{{q1.x, q1.y, q1.z, q1.w}};
+                }
                 const int su = s[u];
                 const R bw_s = rowsT[6 * kWave + su], c_s = rowsT[6 * kWave + 8 + su];
-                kb[u] = h[u] * rfma(bw_s, lam[u], group_sum8(rowsT[su * kWave + lane] * ZZ[u]));
-                ts[u] = rfma(c_s, h[u], tc[u]);
-                const R al = (ts[u] - t0[u]) * inv_len[u];
-                const R gdv = rfma(al, dd[u], d0[u]);
-                tv[u] = rfma(al, dv[u], v0[u]);
+                kb[u] = sc0.v[1] * rfma(bw_s, lam[u], group_sum8(rowsT[su * kWave + lane] * ZZ[u]));
+                ts[u] = rfma(c_s, sc0.v[1], sc0.v[0]);
+                const R al = (ts[u] - sc0.v[2]) * sc0.v[3];
+                const R gdv = rfma(al, sc1.v[3], sc1.v[2]);
+                tv[u] = rfma(al, sc1.v[1], sc1.v[0]);
                 R gde = 0.f;
                 if constexpr (GD) gde = gd_effect(o, gdv);
                 const R G = lane_bcast(Ys, 0), I = lane_bcast(Ys, 1), Glu = lane_bcast(Ys, 2), GLP1 = lane_bcast(Ys, 3),
@@ -539,6 +615,7 @@ __global__ __launch_bounds__(64 * kWsWaves) void solve_bwd_ws_kernel(const AdjAr
                 d[u] = (hact[u][NL - 1] > 0.f) ? dl : 0.f;
                 hd[u][(NL - 1) * kWave + lane] = d[u];         // delta_NL
             }
+            WS_STAMP(3);
 #pragma unroll
             for (int l = NL - 1; l >= 1; --l) {                // hidden matrix l-1 maps h_l -> h_{l+1}
                 R dp[U];
@@ -554,6 +631,7 @@ __global__ __launch_bounds__(64 * kWsWaves) void solve_bwd_ws_kernel(const AdjAr
                     d[u] = (hact[u][l - 1] > 0.f) ? dp[u] : 0.f;
                     hd[u][(l - 1) * kWave + lane] = d[u];      // delta_l
                 }
+                WS_STAMP(3 + NL - l);
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -571,13 +649,18 @@ __global__ __launch_bounds__(64 * kWsWaves) void solve_bwd_ws_kernel(const AdjAr
                         if (--st[u] < 0) {
                             finish_traj(u);
                             start_next(u);
+                        } else {
+                            hp[u] ^= 1;            // the next step's header was gathered while this step's stages ran
                         }
                     } else {
                         --s[u];
                     }
                 }
             }
+            WS_STAMP(8);
             __syncthreads();
+            WS_STAMP(9);
+            WS_TRACE_FLUSH(it, wave);
         }
     } else {
 #pragma unroll
@@ -588,14 +671,14 @@ __global__ __launch_bounds__(64 * kWsWaves) void solve_bwd_ws_kernel(const AdjAr
         // base register + an immediate
         const bool work = a.gnn != nullptr && !(dbg & 1);
         switch (aj) {
-        case 0: ws_acc_loop<NL, U, 0>(recs, hands, tags, n_iter, work, lane, gw, gb, ge); break;
-        case 1: ws_acc_loop<NL, U, 1>(recs, hands, tags, n_iter, work, lane, gw, gb, ge); break;
-        case 2: ws_acc_loop<NL, U, 2>(recs, hands, tags, n_iter, work, lane, gw, gb, ge); break;
-        case 3: ws_acc_loop<NL, U, 3>(recs, hands, tags, n_iter, work, lane, gw, gb, ge); break;
-        case 4: ws_acc_loop<NL, U, 4>(recs, hands, tags, n_iter, work, lane, gw, gb, ge); break;
-        case 5: ws_acc_loop<NL, U, 5>(recs, hands, tags, n_iter, work, lane, gw, gb, ge); break;
-        case 6: ws_acc_loop<NL, U, 6>(recs, hands, tags, n_iter, work, lane, gw, gb, ge); break;
-        default: ws_acc_loop<NL, U, 7>(recs, hands, tags, n_iter, work, lane, gw, gb, ge); break;
+        case 0: ws_acc_loop<NL, U, 0>(recs, hands, tags, n_iter, work, lane, gw, gb, ge, dbg); break;
+        case 1: ws_acc_loop<NL, U, 1>(recs, hands, tags, n_iter, work, lane, gw, gb, ge, dbg); break;
+        case 2: ws_acc_loop<NL, U, 2>(recs, hands, tags, n_iter, work, lane, gw, gb, ge, dbg); break;
+        case 3: ws_acc_loop<NL, U, 3>(recs, hands, tags, n_iter, work, lane, gw, gb, ge, dbg); break;
+        case 4: ws_acc_loop<NL, U, 4>(recs, hands, tags, n_iter, work, lane, gw, gb, ge, dbg); break;
+        case 5: ws_acc_loop<NL, U, 5>(recs, hands, tags, n_iter, work, lane, gw, gb, ge, dbg); break;
+        case 6: ws_acc_loop<NL, U, 6>(recs, hands, tags, n_iter, work, lane, gw, gb, ge, dbg); break;
+        default: ws_acc_loop<NL, U, 7>(recs, hands, tags, n_iter, work, lane, gw, gb, ge, dbg); break;
         }
     }
 
@@ -611,10 +694,10 @@ __global__ __launch_bounds__(64 * kWsWaves) void solve_bwd_ws_kernel(const AdjAr
             if (!isP && ar == rr) {
 #pragma unroll
                 for (int r = 0; r < kMaxH; ++r) {
-                    // accumulator 16 w + n of lane (q, i) is dW[16 w + i][16 q + ((i - n) & 15)]; it is half (w >> 1) of the pair 2 n + (w & 1)
-                    const int w = r >> 4, n = r & 15, i = lane & 15, q = lane >> 4;
-                    const R v = (w >> 1) ? gw[2 * n + (w & 1)].y : gw[2 * n + (w & 1)].x;
-                    R *dst = wt + (size_t)am * kMaxH * kMaxH + (16 * w + i) * kMaxH + 16 * q + ((i - n) & 15);
+                    // accumulator 16 w + c of lane (q, i) is dW[16 w + i][16 q + c]; it is half (w >> 1) of the pair 2 c + (w & 1)
+                    const int w = r >> 4, c = r & 15, i = lane & 15, q = lane >> 4;
+                    const R v = (w >> 1) ? gw[2 * c + (w & 1)].y : gw[2 * c + (w & 1)].x;
+                    R *dst = wt + (size_t)am * kMaxH * kMaxH + (16 * w + i) * kMaxH + 16 * q + c;
                     *dst = (rr == 0) ? v : *dst + v;
                 }
             }
@@ -631,7 +714,7 @@ __global__ __launch_bounds__(64 * kWsWaves) void solve_bwd_ws_kernel(const AdjAr
         for (int jj = 0; jj < kWsA; ++jj) {
             if (aj == jj) {
                 edgeS[(ES::b + am + 1) * kWave + lane] += gb;
-                if (jj >= 4) {
+                if (has_edges<NL>(jj)) {
 #pragma unroll
                     for (int i = 0; i < 9; ++i) edgeS[(ES::w1 + i) * kWave + lane] += ge[i];
                     edgeS[(ES::b + 0) * kWave + lane] += ge[9];
@@ -690,7 +773,7 @@ template <int NL, bool GODE, bool GD> static int launch_ws_g(hipStream_t s, cons
     int two = per_set > blocks * kWsP && !GODE;          // (with the 17 ODE-constant partials the two-trajectory instantiation spills)
 #ifdef HODE_LAB
     static const int dbg = [] { const char *e = getenv("HODE_WS_DBG"); return e ? atoi(e) : 0; }();
-    method |= (dbg & 0xff) << 8;
+    method |= (dbg & 0xcff) << 8;                          // (256 / 512 are the host's switches below)
     if (dbg & 256) two = 0;
     if (dbg & 512) two = 1;
 #endif
@@ -703,6 +786,19 @@ template <int NL> static int launch_ws_nl(hipStream_t s, const AdjArgs<float> &a
     if (a.gode) return gd ? launch_ws_g<NL, true, true>(s, a, method, cus) : launch_ws_g<NL, true, false>(s, a, method, cus);
     return gd ? launch_ws_g<NL, false, true>(s, a, method, cus) : launch_ws_g<NL, false, false>(s, a, method, cus);
 }
+
+#ifdef HODE_LAB
+}  // namespace hode
+// lab library only: the stamps of HODE_WS_DBG bit 1024 (tools/ws_trace.py)
+extern "C" int hode_lab_ws_trace(unsigned long long *dst, int n)
+{
+    using namespace hode;
+    const int total = kWsTraceIts * kWsWaves * kWsTracePts;
+    if (n < total) return -total;
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_ws_trace), sizeof(unsigned long long) * total) == hipSuccess ? total : -1;
+}
+namespace hode {
+#endif
 
 // HODE_EUNSUPPORTED: not a shape / launch this kernel takes (NL = 1, no partial rows) -- the caller runs solve_bwd_kernel
 int launch_solve_bwd_ws(hipStream_t s, const AdjArgs<float> &a, int L, int method, int cus)

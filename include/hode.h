@@ -78,7 +78,8 @@ const char *hode_version(void);
 /* number of MLP parameters for (H hidden, L hidden layers); 13510 for (64,4), 68102 for (128,5) */
 int hode_nn_param_count(int H, int L);
 
-/* bytes of the tape the solve writes for the adjoint: per accepted step {t, h, y[6]}, the grid
+/* bytes of the tape the solve writes for the adjoint: per accepted step {t, h, t0, 1/(t1-t0), v0, v1-v0, d0, d1-d0}
+ * (the step and the constants of its grid interval: time, tVNS and gastric-distension inputs), the grid
  * interval (bit 30 set when the step ended exactly on the grid point closing that interval), and the "stage tape" -- the
  * MLP activations and stage state of every Runge-Kutta stage (tuned path 6 x (L x 64 + 8) reals per step, generic path
  * 6 x (2L x 64 + 8)), so that the adjoint never re-runs the forward.  This is a memory-for-compute trade sized for
