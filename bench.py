@@ -125,6 +125,7 @@ def synth_weights(seed=0):
 
 ODE_DEFAULT = torch.tensor([0.0104, 0.025, 0.003, 5.0, 60.0, 0.1, 50.0, 80.0, 9.0, 7.0, 0.02, 0.01, 1000.0, 2.0,
                             0.05, 0.001, 0.01])
+ODE_NAMES = ["a_GI", "k_I", "rho", "G_b", "I_b", "E_max", "EC_50", "Glu_b", "V_max", "K_m", "k_L", "k_GE0", "IGD_50", "g", "p_7", "p_8", "p_9"]
 
 
 def synth_cohort(B, seed):
@@ -140,6 +141,160 @@ def synth_cohort(B, seed):
     return x0, t, meal, tvns
 
 
+# ---- the Sobol study of the reference's plots/plot_all.py:139-196, its only workload with a published time
+SOBOL_NAMES = ["a_GI", "k_I", "rho", "E_max", "V_max", "K_m", "k_L"]                                        # plot_all.py:139
+SOBOL_BOUNDS = [[0.008, 0.012], [0.02, 0.03], [0.002, 0.004], [0.08, 0.12], [7.0, 11.0], [5.5, 8.5], [0.015, 0.025]]   # :140-148
+
+
+def saltelli_sets(n=1024, seed=0):
+    """Saltelli's design for first / total / second-order indices: n (2 D + 2) rows = 16 384 for n = 1 024, D = 7 -- the row
+    count and block layout (A, AB_1..AB_D, BA_1..BA_D, B per base sample) of SALib's `saltelli.sample(problem, 1024)`
+    (plot_all.py:158).  SALib is not installed here: the base sample comes from SciPy's scrambled Sobol sequence, so the
+    values differ from SALib's, the workload (16 384 single-patient solves over the same box) does not."""
+    from scipy.stats import qmc
+    D = len(SOBOL_NAMES)
+    base = qmc.Sobol(d=2 * D, scramble=True, seed=seed).random(n)
+    lo, hi = np.array(SOBOL_BOUNDS).T
+    A, Bm = lo + base[:, :D] * (hi - lo), lo + base[:, D:] * (hi - lo)
+    rows = np.empty((n, 2 * D + 2, D))
+    rows[:, 0] = A
+    rows[:, -1] = Bm
+    for i in range(D):
+        rows[:, 1 + i] = A
+        rows[:, 1 + i, i] = Bm[:, i]
+        rows[:, 1 + D + i] = Bm
+        rows[:, 1 + D + i, i] = A[:, i]
+    return rows.reshape(-1, D)
+
+
+def sobol_inputs():
+    """plot_all.py:164-165,184-187: x0 = [5, 60, 80, 0, 0, 1], 61 points over 5 h, 75 mmol of glucose at 30 min, no tVNS."""
+    x0 = torch.tensor([5.0, 60.0, 80.0, 0.0, 0.0, 1.0])
+    t = torch.linspace(0, 5, 61)
+    meal = torch.zeros(61)
+    meal[6] = 75.0
+    return x0, t, meal.unsqueeze(0), torch.zeros(1, 61)
+
+
+def sobol_outputs(y):
+    """plot_all.py:191-193 on [S, 61, 6] trajectories: glucose AUC (trapezoid, dx = 5 / 60), insulin peak, mean GLP-1 from the meal on."""
+    xp = torch if torch.is_tensor(y) else np
+    auc = ((y[:, 1:, 0] + y[:, :-1, 0]) * 0.5).sum(1) * (5.0 / 60.0)
+    peak = y[:, :, 1].max(1)
+    peak = peak.values if torch.is_tensor(y) else peak
+    return xp.stack([auc, peak, y[:, 6:, 3].mean(1)], 1)
+
+
+def class_model(dev, seed=0):
+    """HybridODENN (the drop-in class) carrying the benchmark's G0-style weights."""
+    from models import HybridODENN
+    torch.manual_seed(0)
+    m = HybridODENN(device=dev)
+    with torch.no_grad():
+        off, w = 0, synth_weights(seed)
+        for p in m.nn_residual.parameters():
+            p.copy_(w[off:off + p.numel()].reshape(p.shape))
+            off += p.numel()
+    return m
+
+
+def sobol_leg(dev, n=1024, host=None):
+    """All 16 384 parameter sets x 1 patient of the Sobol study through HybridODENN.forward_ode_sets: ONE launch, the network
+    shared (HODE_LAYERS_NN_SHARED).  The reference runs them one model.forward at a time: "~5-10 minutes" (README.md:248)."""
+    sets = saltelli_sets(n)
+    m = class_model(dev)
+    x0, t, meal, tvns = (v.to(dev) for v in sobol_inputs())
+    ode_sets = {k: torch.as_tensor(sets[:, i], dtype=torch.float32, device=dev) for i, k in enumerate(SOBOL_NAMES)}
+
+    def run():
+        return m.forward_ode_sets(ode_sets, x0, t, {"meal": meal, "tVNS": tvns})
+    y = run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    y = run()
+    e1.record()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    out3 = sobol_outputs(y)
+    torch.cuda.synchronize()
+    wall_all = time.perf_counter() - t0
+    st = m.last_solve_info
+    res = {"workload": f"plots/plot_all.py:139-196: {sets.shape[0]} Saltelli parameter sets (N = {n}, 7 mechanistic constants, second-order design) "
+                       "x 1 patient, x0 = [5, 60, 80, 0, 0, 1], 61 points over 5 h, 75 mmol meal pulse at 30 min; DP5(4) 1e-6 / 1e-8, fp32, "
+                       "4x64 network shared by all sets",
+           "call": "HybridODENN.forward_ode_sets (class surface) -> one hode_solve_fwd_f32 launch, n_sets = B = 16 384",
+           "sets": int(sets.shape[0]), "seconds": wall, "seconds_with_outputs": wall_all, "kernel_ms": e0.elapsed_time(e1),
+           "value": sets.shape[0] / wall, "unit": "patient-trajectories/s", "trajectories_ok": int((st["status"] == 0).sum()),
+           "mean_steps": float(st["nsteps"].float().mean()),
+           "outputs_mean": dict(zip(["glucose_auc", "insulin_peak", "glp1_response"], out3.double().mean(0).tolist())),
+           "sampling": "SciPy scrambled Sobol base sample in Saltelli's block layout (SALib absent: other values, same workload)",
+           "vs_reference_published": {"published": "~5-10 minutes (README.md:248, the reference's only timing that matches its code)",
+                                      "speedup_vs_300_s": 300.0 / wall, "speedup_vs_600_s": 600.0 / wall}}
+    if host is not None and host.get("sobol_reference_style"):
+        r = host["sobol_reference_style"]
+        res["reference_style_this_box"] = dict(r, speedup=r["seconds_for_16384_one_thread"] / wall)
+    return res
+
+
+def class_path(dev, x0, t, meal, tvns, headline_ms):
+    """What a user of the drop-in CLASSES gets (SURVEY 8d defines the metric on HybridODENN.forward): the forward at the
+    benchmark size, and one optimisation step of reference train/train_hybrid.py:237-261 (zero_grad -> loss -> backward ->
+    clip_grad_norm_ -> Adam.step) at the reference's own batch (32 windows x 61 points, configs/default.yaml:19) and at 4 096 x 241."""
+    m = class_model(dev)
+    B = x0.shape[0]
+    ext = {"meal": meal, "tVNS": tvns}
+    with torch.no_grad():
+        for _ in range(2):
+            y = m(x0, t, ext)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record()
+        for _ in range(5):
+            y = m(x0, t, ext)
+        e1.record()
+        torch.cuda.synchronize()
+        wall = (time.perf_counter() - t0) / 5
+    fwd = {"call": "HybridODENN.forward under torch.no_grad()", "patients": B, "grid_points": int(t.shape[-1]), "ms_wall": wall * 1e3,
+           "ms_events": e0.elapsed_time(e1) / 5, "value": B / wall, "unit": "patient-trajectories/s",
+           "over_headline_kernel_time": wall * 1e3 / headline_ms}
+    steps = []
+    for Bs, Ts, n in ((32, 61, 30), (B, int(t.shape[-1]), 4)):
+        xs, ts_, ms_, vs_ = (v.to(dev) for v in synth_cohort(Bs, 1000))
+        ts_, ms_, vs_ = ts_[:Ts].contiguous(), ms_[:, :Ts].contiguous(), vs_[:, :Ts].contiguous()
+        mm = class_model(dev)
+        with torch.no_grad():
+            obs = mm(xs, ts_, {"meal": ms_, "tVNS": vs_}) + 0.1 * torch.randn(Bs, Ts, 6, device=dev, generator=torch.Generator(dev).manual_seed(5))
+        batch = {"initial_state": xs, "observations": obs, "time_points": ts_, "external_inputs": {"meal": ms_, "tVNS": vs_}}
+        opt = torch.optim.Adam(mm.parameters(), lr=1e-3)
+
+        def step():
+            opt.zero_grad()
+            loss = mm.loss(batch, 1.0, 0.01)
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(mm.parameters(), 5.0)
+            opt.step()
+            return loss
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record()
+        for _ in range(n):
+            loss = step()
+        e1.record()
+        host = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        steps.append({"windows": Bs, "grid_points": Ts, "ms_wall": wall / n * 1e3, "ms_host_issue": host / n * 1e3,
+                      "ms_events": e0.elapsed_time(e1) / n, "value": Bs * n / wall, "unit": "windows/s", "loss": float(loss)})
+    return {"forward": fwd, "train_step": {"call": "zero_grad -> HybridODENN.loss(batch, 1.0, 0.01) (data + physics + L2) -> backward -> "
+                                                   "clip_grad_norm_(5.0) -> torch.optim.Adam.step (train/train_hybrid.py:237-261)", "cases": steps}}
+
+
 def train_problem(dev, x0, t, meal, tvns, ode, nn_teacher, rank):
     """Observations of this rank's shard (teacher trajectories + N(0, 0.1^2) noise, seeded per rank) and the common student
     initialisation of the training leg -- also used by tests/test_bench_contract_gpu.py to rebuild the 2-rank step in one process."""
@@ -151,7 +306,7 @@ def train_problem(dev, x0, t, meal, tvns, ode, nn_teacher, rank):
     return obs, student
 
 
-def cpu_baseline(c_sample, ref_sample=1024, ref_one_thread=128):
+def cpu_baseline_host(c_sample, ref_sample=1024, ref_one_thread=128):
     """The reference's CPU path beside the GPU number, on this box's host cores:
       * reference-style (the headline of this object): per-patient scipy.integrate.solve_ivp(method='RK45', 1e-6 / 1e-8)
         loop with an fp32 torch-CPU RHS -- what reference models/hybrid_ode_nn.py:184-256 does, restated over this repo's own
@@ -199,6 +354,30 @@ def cpu_baseline(c_sample, ref_sample=1024, ref_one_thread=128):
            "c_port": {"value": c_sample / dtc, "unit": "patient-trajectories/s", "cores": ncores, "kind": "port",
                       "per_core": c_sample / dtc / ncores,
                       "sample": f"{c_sample} trajectories, C oracle (the kernel's own grid-broken DP5(4), fp32), {ncores} threads, {dtc:.1f} s wall"}}
+    # the Sobol study's per-solve cost in the reference's style on this box: model.forward(solver='dopri5') = SciPy DOP853 at
+    # 1e-6 / 1e-8 (models/hybrid_ode_nn.py:174-181), one patient per call, 24 of the 16 384 sets on one thread
+    sx0, st_, smeal, stv = (v.numpy() for v in sobol_inputs())
+    ssets = saltelli_sets(1024)[:24]
+    torch.set_num_threads(1)
+    t0 = time.perf_counter()
+    for row in ssets:
+        o2 = ode.copy()
+        for name, val in zip(SOBOL_NAMES, row):
+            o2[ODE_NAMES.index(name)] = np.float32(val)
+        RS.solve(sx0[None], st_, {"meal": smeal, "tVNS": stv}, nn, o2, H, L, solver="dopri5")
+    dts = time.perf_counter() - t0
+    torch.set_num_threads(torch_threads)
+    out["sobol_reference_style"] = {"seconds_per_set_one_thread": dts / len(ssets), "seconds_for_16384_one_thread": dts / len(ssets) * 16384,
+                                    "sample": f"{len(ssets)} of the 16 384 sets, solve_ivp(DOP853, 1e-6 / 1e-8) per set, fp32 torch-CPU RHS, one thread"}
+    out["_host"] = (x0, t, meal, tvns, nn, ode, n1, y_ref)
+    return out
+
+
+def cpu_baseline_gpu(out):
+    """The half of cpu_baseline that needs the GPU: parity of the HIP path with the checkers on the benchmark cohort."""
+    from oracle import oracle as O
+    from oracle import reference_style as RS
+    x0, t, meal, tvns, nn, ode, n1, y_ref = out.pop("_host")
     out["parity_check"] = parity_check(O, x0[:16], t, meal[:16], tvns[:16], nn, ode)
     # what the reference itself would have returned for the first trajectories (default tolerances: ~1e-2 with meals, SURVEY F6)
     import hode
@@ -301,8 +480,14 @@ def generic_path(dev):
             return e0.elapsed_time(e1) / reps
         ms_f = timed(lambda: hode.solve_fwd(x0, t, meal, tv, None, ode, nn, Hg, Lg, want_tape=True, tape=st.tape))
         ms_b = timed(lambda: hode.solve_bwd(st, gy))
+        flop_rhs = 2 * (9 * Hg + (Lg - 1) * Hg * Hg + 6 * Hg) + 80          # 134 992 for 128 x 5
+        f_fwd = float(st.nfev.double().sum()) * flop_rhs
+        f_adj = float(st.nsteps.double().sum()) * 6 * 2 * flop_rhs
         rows.append({"patients": Bg, "grid_points": Tg, "forward_with_tape_ms": ms_f, "adjoint_ms": ms_b,
-                     "trajectories_per_s_train": Bg / (ms_f + ms_b) * 1e3, "trajectories_ok": int((st.status == 0).sum())})
+                     "trajectories_per_s_train": Bg / (ms_f + ms_b) * 1e3, "trajectories_ok": int((st.status == 0).sum()),
+                     "roofline": {"bound": "valu_fp32", "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "flop_per_rhs": flop_rhs,
+                                  "forward_with_tape": {"achieved": f_fwd / (ms_f * 1e-3) / 1e12, "frac": f_fwd / (ms_f * 1e-3) / 1e12 / PEAK_FP32_TFLOPS},
+                                  "adjoint": {"achieved": f_adj / (ms_b * 1e-3) / 1e12, "frac": f_adj / (ms_b * 1e-3) / 1e12 / PEAK_FP32_TFLOPS}}})
     return {"workload": "MLP 9 -> 128 x 5 -> 6 (67 k parameters), DP5(4), fp32, forward with tape + adjoint",
             "kernels": "solve_fwd_generic_kernel / solve_bwd_generic_kernel: teams of 4-8 waves per trajectory", "cases": rows}
 
@@ -370,7 +555,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--patients-per-gpu", type=int, default=4096)
+    ap.add_argument("--patients-per-gpu", type=int, default=0, help="default: 4 096 (BASELINE config[1] per GPU); with --gpus 8 "
+                    "8 192 = BASELINE config[3], the 65 536-patient cohort over the node")
     ap.add_argument("--train-steps", type=int, default=5)
     ap.add_argument("--cpu-sample", type=int, default=32768, help="trajectories of the C-oracle leg of cpu_baseline")
     ap.add_argument("--ref-sample", type=int, default=1024, help="trajectories of the reference-style (solve_ivp loop) leg")
@@ -379,6 +565,8 @@ def main():
     ap.add_argument("--no-data-side", action="store_true")
     ap.add_argument("--no-vi", action="store_true")
     ap.add_argument("--no-generic", action="store_true", help="skip the generic-path (128 x 5 network) block")
+    ap.add_argument("--no-sobol", action="store_true", help="skip the Sobol-study leg (16 384 parameter sets, plots/plot_all.py:139-196)")
+    ap.add_argument("--no-class-path", action="store_true", help="skip the class-surface leg (HybridODENN.forward / loss / optimiser step)")
     ap.add_argument("--vi-patients", type=int, default=8192, help="patients of the VI leg (BASELINE config 5: 8 192 per GPU x 16 draws)")
     ap.add_argument("--cohort", type=int, default=65536, help="subjects of the data-side leg (4GI generator + windows)")
     ap.add_argument("--no-zscore", action="store_true", help="skip the z-scored-regime leg (profiling: the headline kernel's "
@@ -397,6 +585,13 @@ def main():
     if args.gpus > 1 and world == 1:
         raise SystemExit("for --gpus N > 1 launch with torch.distributed.run (one rank per GPU)")
     ensure_built(may_build=not (args.no_build or os.environ.get("HODE_NO_BUILD")))   # before any GPU / collective call
+    if args.patients_per_gpu <= 0:
+        args.patients_per_gpu = 8192 if args.gpus == 8 else 4096
+    # the host-only half of cpu_baseline (reference-style solve_ivp loops: one thread, then one spawned worker process per core;
+    # the C oracle on threads) runs BEFORE the first call that initialises the GPU: no process is started from a GPU-initialised one
+    host = None
+    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+        host = cpu_baseline_host(args.cpu_sample, args.ref_sample)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     ndev = torch.cuda.device_count()
@@ -570,8 +765,11 @@ def main():
             "unit": "patient-trajectories/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE config[1]: 4096-patient 4GI-style synthetic cohort per GPU, DP5(4) adaptive "
-                                   "(rtol 1e-6, atol 1e-8), ODE + 4x64 MLP residual, fp32, forward solve, T=241",
+            "config": {"workload": (f"BASELINE config[3]: {B_total}-patient 4GI-style synthetic cohort sharded over {world} GPUs ({B_total // world} per GPU)"
+                                    if world > 1 and B_total // world == 8192 else
+                                    f"BASELINE config[1]: {B_total // world}-patient 4GI-style synthetic cohort per GPU") +
+                                   ", DP5(4) adaptive (rtol 1e-6, atol 1e-8), ODE + 4x64 MLP residual, fp32, forward solve, T=241"
+                                   + ("; train_step = config[3]'s step: adjoint + ONE RCCL all-reduce of the gradients + fused Adam" if world > 1 else ""),
                        "patients_per_gpu": B_total / world, "patients_total": B_total, "grid_points": T, "parallelism": f"patients sharded x{world}, no data-path collective",
                        "trajectories_ok": ok, "mean_steps": nsteps / B, "mean_nfev": nfev / B},
             "roofline": {"bound": "valu_fp32", "bound_detail": "fp32 vector FMA issue (MFMA deliberately unused, north_star); peak = "
@@ -592,8 +790,13 @@ def main():
             out["generic_path"] = generic_path(dev)
         if world == 1 and not args.no_data_side:
             out["data_side"] = data_side(dev, args.cohort, cpu=not args.no_cpu_baseline)
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.ref_sample)
+        if world == 1 and not args.no_sobol:
+            out["sobol"] = sobol_leg(dev, host=host)
+        if world == 1 and not args.no_class_path:
+            out["class_path"] = class_path(dev, x0, t, meal, tvns, kern_ms)
+        if host is not None:
+            host.pop("sobol_reference_style", None)
+            out["cpu_baseline"] = cpu_baseline_gpu(host)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

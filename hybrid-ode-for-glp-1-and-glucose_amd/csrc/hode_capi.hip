@@ -24,8 +24,11 @@ int solve_fwd(void *stream, int B, int T, const R *x0, const R *t, int t_batched
     if (n_sets < 1 || (B % n_sets) != 0 || max_steps < 1) return HODE_EINVAL;
     if (method != HODE_METHOD_DP54 && method != HODE_METHOD_RK4) return HODE_EINVAL;
     if (!(rtol >= 0) || !(atol >= 0) || (method == HODE_METHOD_DP54 && rtol == 0 && atol == 0)) return HODE_EINVAL;
-    if (H < 1 || H > HODE_MAX_HIDDEN || layers_of(L) < 1 || layers_of(L) > HODE_MAX_LAYERS || act_of(L) > HODE_ACT_LEAKY_RELU || (L >> 16) != 0)
+    if (H < 1 || H > HODE_MAX_HIDDEN || layers_of(L) < 1 || layers_of(L) > HODE_MAX_LAYERS || act_of(L) > HODE_ACT_LEAKY_RELU || (L >> 17) != 0)
         return HODE_EUNSUPPORTED;
+    const bool nn_shared = (L & HODE_LAYERS_NN_SHARED) != 0;   // one network for every set of constants (forward only)
+    if (nn_shared && tape) return HODE_EUNSUPPORTED;          // (the adjoint writes one gradient row per parameter set)
+    L &= 0xffff;
     if (B == 0) return HODE_OK;
     SolveArgs<R> a;
     a.B = B; a.T = T; a.t_batched = t_batched ? 1 : 0;
@@ -39,6 +42,7 @@ int solve_fwd(void *stream, int B, int T, const R *x0, const R *t, int t_batched
     a.tape_stage = tape ? (R *)((char *)tape + tape_stage_offset(B, max_steps, sizeof(R))) : nullptr;
     a.L = layers_of(L);
     a.act = act_of(L);
+    a.nn_stride = nn_shared ? 0 : a.P;
     if (!tuned_shape(H, L)) return launch_solve_fwd_generic<R>((hipStream_t)stream, a, method);
     return launch_solve_fwd<R>((hipStream_t)stream, a, layers_of(L), method);
 }

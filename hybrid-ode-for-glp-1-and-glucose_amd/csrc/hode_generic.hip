@@ -735,7 +735,7 @@ __global__ __launch_bounds__(64 * NW, (sizeof(R) == 8) ? 1 : (NB > 0 ? 2 : 4)) v
     OdeP<R> o;
     ode_load(o, a.ode_p + 17 * set);
     __shared__ R edge_img[kEdgeImageMax];                // the edge parameters of this trajectory's set (EdgeImage)
-    const StreamNet<R> net{a.nn_p + (size_t)set * a.P, a.H, a.L, a.act};
+    const StreamNet<R> net{a.nn_p + (size_t)set * a.nn_stride, a.H, a.L, a.act};
     EdgeImage<R>::fill(edge_img, net, threadIdx.x, 64 * NW);
     __syncthreads();
     RhsStream<R, NW, EdgeImage<R>, CC, NB> rhs{net, EdgeImage<R>{edge_img, a.H, a.L}, o, lane, part, xch, {}};

@@ -17,6 +17,7 @@ template <typename R> struct SolveArgs {
     R *tape_stage;      // [B][max_steps][6 stages][tape_slot_elems]: layer activations + stage state of every accepted step
     int L;              // hidden layers (plain count)
     int act;            // HODE_ACT_* (generic kernels; the tuned ones are ReLU)
+    int nn_stride;      // reals between the networks of consecutive parameter sets: P, or 0 for one shared network (HODE_LAYERS_NN_SHARED)
 };
 
 template <typename R> struct AdjArgs {

@@ -23,7 +23,7 @@ __global__ __launch_bounds__(64, LB) void solve_fwd_kernel(const SolveArgs<R> a)
     tableau_rows_store<R>(rows, METHOD, lane, 64);
     if (lane < 8) cvec[lane] = (R)kTableau[METHOD].c[lane];
     MlpRegs<R, NL> W;
-    mlp_load<R, NL>(W, a.nn_p + (size_t)set * a.P, a.H, lane, wstage);
+    mlp_load<R, NL>(W, a.nn_p + (size_t)set * a.nn_stride, a.H, lane, wstage);
     OdeP<R> o;
     ode_load(o, a.ode_p + 17 * set);
     __syncthreads();

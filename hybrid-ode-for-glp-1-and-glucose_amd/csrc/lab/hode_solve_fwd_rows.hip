@@ -178,7 +178,7 @@ __global__ __launch_bounds__(64 * kRowsWaves, kRowsWaves) void solve_fwd_rows_ke
     if (threadIdx.x < 8) cvec[threadIdx.x] = (float)kTableau[METHOD].c[threadIdx.x];
     MlpRows<NL> W;
     W.xh = xh; W.flags = flags; W.lane = lane; W.wave = wave;
-    W.load(a.nn_p + (size_t)set * a.P, a.H);
+    W.load(a.nn_p + (size_t)set * a.nn_stride, a.H);
     OdeP<float> o;
     ode_load(o, a.ode_p + 17 * set);
     __syncthreads();

@@ -29,7 +29,7 @@ __global__ __launch_bounds__(64 * WPB, (WPB >= 4) ? WPB / 4 : 1) void solve_fwd_
     float *ybuf = cvec + 8 + (size_t)wave * (kWave + 8);                    // [WPB][64 + 8]
     const int set = blockIdx.y;
     const int per_set = a.B / a.n_sets;
-    const float *__restrict__ nn_set = a.nn_p + (size_t)set * a.P;
+    const float *__restrict__ nn_set = a.nn_p + (size_t)set * a.nn_stride;
 
     wimg_store(img, nn_set, a.H, NL - 1, threadIdx.x, 64 * WPB);
     tableau_rows_store<float>(rows, METHOD, threadIdx.x, 64 * WPB);

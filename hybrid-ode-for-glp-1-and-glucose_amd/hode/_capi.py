@@ -59,6 +59,7 @@ def version():
 
 
 ACT_RELU, ACT_TANH, ACT_ELU, ACT_LEAKY_RELU = 0, 1, 2, 3
+NN_SHARED = 1 << 16          # HODE_LAYERS_NN_SHARED (hode_solve_fwd_* only)
 
 
 def layers(L, act=ACT_RELU):
@@ -145,10 +146,11 @@ def tape_nbytes(B, max_steps, elem_size, L, H=64):
 
 
 def solve_fwd(x0, t, meal, tvns, gd, ode_p, nn_p, H, L, method=METHOD_DP54, rtol=1e-6, atol=1e-8,
-              max_steps=None, n_sets=1, want_tape=False, tape=None):
+              max_steps=None, n_sets=1, want_tape=False, tape=None, nn_shared=False):
     """Forward solve.  want_tape=True records what the adjoint needs; pass `tape=` (a uint8 tensor of at least
     tape_nbytes(...) bytes, e.g. the `.tape` of an earlier solution of the same shape) to reuse the buffer
-    instead of allocating several GB per call."""
+    instead of allocating several GB per call.
+    nn_shared=True: `nn_p` is ONE network used by all n_sets sets of ODE constants (HODE_LAYERS_NN_SHARED; forward only)."""
     _need_gpu(x0)
     dt, dev = x0.dtype, x0.device
     x0 = x0.contiguous()
@@ -160,8 +162,10 @@ def solve_fwd(x0, t, meal, tvns, gd, ode_p, nn_p, H, L, method=METHOD_DP54, rtol
         raise HodeError("batched time grid must be [B,T]")
     meal, tvns, gd = (_prep(v, dt, dev) for v in (meal, tvns, gd))
     ode_p, nn_p = _prep(ode_p, dt, dev), _prep(nn_p, dt, dev)
-    if nn_p.numel() != n_sets * n_params(H, L) or ode_p.numel() != 17 * n_sets:
+    if nn_p.numel() != (1 if nn_shared else n_sets) * n_params(H, L) or ode_p.numel() != 17 * n_sets:
         raise HodeError("parameter vector size does not match (H, L, n_sets)")
+    if nn_shared and (want_tape or tape is not None):
+        raise HodeError("nn_shared is a forward-only option (the adjoint returns one gradient row per parameter set)")
     if max_steps is None:
         # accepted-step budget per trajectory.  With a tape every step costs 6*(L+1)*256 B of HBM (stage
         # tape), so the default is tighter there; a trajectory that needs more reports status 1.
@@ -189,7 +193,8 @@ def solve_fwd(x0, t, meal, tvns, gd, ode_p, nn_p, H, L, method=METHOD_DP54, rtol
     fn = getattr(load(), f"hode_solve_fwd_{_sfx(dt)}")
     rc = fn(_stream(), C.c_int(B), C.c_int(T), _ptr(x0), _ptr(t), C.c_int(t_batched),
             _ptr(meal), C.c_int(_mode(meal, B, T)), _ptr(tvns), C.c_int(_mode(tvns, B, T)),
-            _ptr(gd), C.c_int(_mode(gd, B, T)), _ptr(ode_p), _ptr(nn_p), C.c_int(n_sets), C.c_int(H), C.c_int(L),
+            _ptr(gd), C.c_int(_mode(gd, B, T)), _ptr(ode_p), _ptr(nn_p), C.c_int(n_sets), C.c_int(H),
+            C.c_int(L | (NN_SHARED if nn_shared else 0)),
             C.c_int(method), C.c_double(rtol), C.c_double(atol), C.c_int(max_steps), _ptr(s.y), _ptr(s.status),
             _ptr(s.nsteps), _ptr(s.nfev), _ptr(s.tape))
     _check(rc, "hode_solve_fwd")

@@ -498,7 +498,7 @@ class HybridODENN(nn.Module):
         return x0.contiguous(), t, ins
 
     def _solve(self, initial_state, t_span, external_inputs, solver, rtol, atol, params=None, n_sets=1,
-               nn_flat=None, ode_vec=None, differentiable=None):
+               nn_flat=None, ode_vec=None, differentiable=None, nn_shared=False):
         self._check_supported()
         dev = _compute_device()
         x0, t, ins = self._prep_inputs(initial_state, t_span, external_inputs, dev)
@@ -507,7 +507,7 @@ class HybridODENN(nn.Module):
         method = _SOLVERS.get(str(solver).lower())
         if method is None:
             raise ValueError(f"unknown solver {solver!r}; known: {sorted(_SOLVERS)}")
-        diff = self.adjoint if differentiable is None else differentiable
+        diff = (self.adjoint if differentiable is None else differentiable) and not nn_shared
         info = {}
         nl = self.nn_residual
         if diff and torch.is_grad_enabled():
@@ -517,7 +517,7 @@ class HybridODENN(nn.Module):
             with torch.no_grad():
                 sol = hode.solve_fwd(x0.contiguous(), t, ins["meal"], ins["tVNS"], ins["GD"], ode_vec.detach(),
                                      nn_flat.detach(), nl.hidden_dim, nl.hip_layers, method=method, rtol=float(rtol),
-                                     atol=float(atol), n_sets=n_sets)
+                                     atol=float(atol), n_sets=n_sets, nn_shared=nn_shared)
             y = sol.y
             info = {"status": sol.status, "nsteps": sol.nsteps, "nfev": sol.nfev}
         self.last_solve_info = info
@@ -591,6 +591,49 @@ class HybridODENN(nn.Module):
                 u[k] = v
         y = self._solve(x0.repeat(S, 1), rep(t) if t.dim() == 2 else t, u, solver, rtol, atol, n_sets=S,
                         nn_flat=nn_flat, ode_vec=ode_vec)
+        self._warn_failures(self.last_solve_info)
+        y = y.reshape(S, B, y.shape[1], 6).to(self.device)
+        return y[:, 0] if single else y
+
+    def forward_ode_sets(self, ode_sets: Dict[str, torch.Tensor], initial_state: torch.Tensor, t_span: torch.Tensor,
+                         external_inputs: Optional[Dict[str, torch.Tensor]] = None, solver: str = "dopri5",
+                         rtol: float = 1e-6, atol: float = 1e-8) -> torch.Tensor:
+        """S sets of MECHANISTIC constants x B patients through the model's one network, in ONE launch -> [S, B, T, 6]
+        ([S, T, 6] for a (6,) initial state).  `ode_sets`: constant name (an ODECore buffer, with or without the `ode_`
+        prefix of forward_with_params) -> S values; constants not named keep the model's value.
+
+        The batched form of the Sobol study of the reference's plots/plot_all.py:139-196: there, 16 384 Saltelli samples of
+        seven constants are written into `model.ode_core` one at a time (`setattr(..., torch.tensor(value))`, :179-181, i.e.
+        rounded to fp32) and `model.forward` integrates one patient per sample ("~5-10 minutes", README.md:248).  Here the
+        samples ride in the kernel's parameter-set dimension with the network shared (HODE_LAYERS_NN_SHARED).  Forward only,
+        never differentiated (the study only reads trajectories)."""
+        dev = _compute_device()
+        cols = {}
+        for name, vals in ode_sets.items():
+            key = name[4:] if name.startswith("ode_") else name
+            if key not in ODE_PARAM_NAMES:
+                raise ValueError(f"unknown mechanistic constant {name!r}; known: {list(ODE_PARAM_NAMES)}")
+            cols[ODE_PARAM_NAMES.index(key)] = torch.as_tensor(vals).reshape(-1).to(dev, torch.float32)
+        if not cols:
+            raise ValueError("forward_ode_sets needs at least one constant to vary")
+        S = {int(v.numel()) for v in cols.values()}
+        if len(S) != 1:
+            raise ValueError("every constant needs the same number of samples")
+        S = S.pop()
+        nn_flat, ode_vec = self._params_on(dev)
+        ode_mat = ode_vec.reshape(1, -1).repeat(S, 1)
+        for j, v in cols.items():
+            ode_mat[:, j] = v
+        single = initial_state.dim() == 1
+        x0 = initial_state.unsqueeze(0) if single else initial_state
+        B = x0.shape[0]
+        rep = lambda v: torch.as_tensor(v).repeat(*([S] + [1] * (torch.as_tensor(v).dim() - 1)))  # noqa: E731
+        t = torch.as_tensor(t_span)
+        u = {k: (rep(v) if torch.as_tensor(v).dim() >= 1 and torch.as_tensor(v).numel() > 1 else v)
+             for k, v in (external_inputs or {}).items()}
+        with torch.no_grad():
+            y = self._solve(x0.repeat(S, 1), rep(t) if t.dim() == 2 else t, u, solver, rtol, atol, n_sets=S,
+                            nn_flat=nn_flat, ode_vec=ode_mat.reshape(-1), nn_shared=True)
         self._warn_failures(self.last_solve_info)
         y = y.reshape(S, B, y.shape[1], 6).to(self.device)
         return y[:, 0] if single else y

@@ -68,6 +68,10 @@ extern "C" {
 #define HODE_ACT_ELU 2
 #define HODE_ACT_LEAKY_RELU 3
 #define HODE_LAYERS(L, act) (((L) & 0xff) | ((act) << 8))
+/* hode_solve_fwd_* only: OR into `L` when nn_p holds ONE network shared by all n_sets sets of mechanistic constants (ode_p stays
+ * [n_sets][17]).  The Sobol study of plots/plot_all.py:139-196 integrates 16 384 constant sets through one trained network: shared,
+ * the launch reads 54 KB of weights instead of 885 MB of copies. */
+#define HODE_LAYERS_NN_SHARED (1 << 16)
 #define HODE_MAX_HIDDEN 128
 #define HODE_MAX_LAYERS 8
 #define HODE_TUNED_HIDDEN 64 /* envelope of the register-resident kernels */

@@ -61,3 +61,27 @@ def test_binary_stamp_follows_the_sources(tmp_path, monkeypatch):
     assert not _build.is_current()
     with pytest.raises(RuntimeError, match="may not start a build"):
         _build.ensure(may_build=False)
+
+
+def test_saltelli_design_of_the_sobol_leg():
+    """bench.py's stand-in for SALib's saltelli.sample(problem, 1024) (reference plots/plot_all.py:139-158): N (2 D + 2) rows in the
+    block layout A, AB_1..AB_D, BA_1..BA_D, B, inside the bounds of :140-148; the three outputs follow :191-193."""
+    import numpy as np
+    import bench
+    s = bench.saltelli_sets(1024)
+    D = len(bench.SOBOL_NAMES)
+    assert s.shape == (1024 * (2 * D + 2), D) == (16384, 7)
+    lo, hi = np.array(bench.SOBOL_BOUNDS).T
+    assert (s >= lo).all() and (s <= hi).all()
+    blk = s.reshape(1024, 2 * D + 2, D)
+    A, B = blk[:, 0], blk[:, -1]
+    for i in range(D):
+        other = [j for j in range(D) if j != i]
+        assert np.array_equal(blk[:, 1 + i][:, other], A[:, other]) and np.array_equal(blk[:, 1 + i][:, i], B[:, i])
+        assert np.array_equal(blk[:, 1 + D + i][:, other], B[:, other]) and np.array_equal(blk[:, 1 + D + i][:, i], A[:, i])
+    assert np.array_equal(bench.saltelli_sets(1024), s)           # seeded
+    y = np.random.default_rng(0).random((5, 61, 6))
+    want = np.stack([np.trapz(y[:, :, 0], dx=5 / 60, axis=1), y[:, :, 1].max(1), y[:, 6:, 3].mean(1)], 1)
+    assert np.allclose(bench.sobol_outputs(y), want, rtol=1e-13)
+    x0, t, meal, tvns = bench.sobol_inputs()
+    assert x0.tolist() == [5.0, 60.0, 80.0, 0.0, 0.0, 1.0] and t.shape == (61,) and float(meal[0, 6]) == 75.0 and float(meal.sum()) == 75.0
