@@ -87,12 +87,14 @@ __global__ __launch_bounds__(256) void mse_kernel(int64_t n4, int64_t n, const f
     for (int64_t i = tid; i < n4; i += stride) {
         const float4 a = y4[i], b = o4[i];
         const float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z, dw = a.w - b.w;
-        acc += (double)(dx * dx + dy * dy) + (double)(dz * dz + dw * dw);
+        // squares and sums in fp64: the value then does not depend on how a launch groups the elements into 16-byte words -- a batch
+        // summed piece by piece (tape-budget chunks of any size, also odd ones) gives the sum of the whole to 1e-16, not 1e-9
+        acc += ((double)dx * dx + (double)dy * dy) + ((double)dz * dz + (double)dw * dw);
         if (gy) g4[i] = make_float4(2.f * scale * dx, 2.f * scale * dy, 2.f * scale * dz, 2.f * scale * dw);
     }
     for (int64_t i = n4 * 4 + tid; i < n; i += stride) {   // tail
         const float d = y[i] - obs[i];
-        acc += (double)(d * d);
+        acc += (double)d * d;
         if (gy) gy[i] = 2.f * scale * d;
     }
     // one fp64 atomic per WORKGROUP: 8 192 same-address atomics (one per wave of a 2 048-block grid) serialise at the memory

@@ -103,6 +103,41 @@ def _tape_budget(dev, need: int = 0):
 TAPE_STEP_MARGIN = (32, 4)        # steps = (T-1) + max(margin[0], (T-1) // margin[1])
 
 
+# A taped solve whose WHOLE tape at the no-grad step budget (8 (T-1) + 64 steps) stays below this is given that budget straight
+# away: no trajectory can run out of tape steps, so there is nothing to retry and -- what matters at the reference's batch sizes
+# (32 windows x 61 points: 110 MB) -- no host synchronisation between the forward solve and the adjoint: the host queues the whole
+# optimisation step ahead of the device instead of waiting ~0.35 ms for the forward in every step (tools/prof_class_step.py).
+SMALL_TAPE_BYTES = 2 << 30
+
+
+def _small_tape_steps(n_traj, T, method, elem, L, H, override):
+    """The no-grad step budget when the tape of `n_traj` trajectories at that budget is small (SMALL_TAPE_BYTES), else None."""
+    if override is not None or method == hode.METHOD_RK4:
+        return None
+    big = _eval_steps(T, method)
+    return big if n_traj * hode.capi.tape_nbytes(1, big, elem, L, H) <= SMALL_TAPE_BYTES else None
+
+
+class _FlatNN(torch.autograd.Function):
+    """The flat parameter vector the kernels take, WITHOUT the torch.cat of ten tensors per step: the ten parameters are views
+    of one buffer (HybridODENN._nn_flat_store), forward hands that buffer out, backward cuts the gradient into ten views."""
+
+    @staticmethod
+    def forward(ctx, flat, *params):
+        ctx.shapes = [p.shape for p in params]
+        return flat.view(-1)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        outs, off = [], 0
+        for shp in ctx.shapes:
+            n = shp.numel()
+            outs.append(g[off:off + n].view(shp))
+            off += n
+        return (None, *outs)
+
+
 def _tape_steps(T, method, override=None):
     if method == hode.METHOD_RK4:
         return max(T - 1, 1)
@@ -214,7 +249,7 @@ class _SolveFn(torch.autograd.Function):
     def forward(ctx, x0, nn_flat, ode_vec, t, meal, tvns, gd, H, L, method, rtol, atol, n_sets, info, tape_steps=None):
         need_tape = any(ctx.needs_input_grad[:3])
         B, T = x0.shape[0], t.shape[-1]
-        steps = _tape_steps(T, method, tape_steps)
+        steps = (_small_tape_steps(B, T, method, x0.element_size(), L, H, tape_steps) if need_tape else None) or _tape_steps(T, method, tape_steps)
         per_traj = hode.capi.tape_nbytes(1, steps, x0.element_size(), L, H)
         budget = _tape_budget(x0.device, B * per_traj) if need_tape else 0
         ctx.chunked = need_tape and B * per_traj > budget
@@ -310,7 +345,7 @@ class _GaussLikFn(torch.autograd.Function):
         grads = any(need[:3])
         B, T = x0.shape[0], t.shape[-1]
         P = nn_flat.numel() // S
-        steps = _tape_steps(T, method, tape_steps)
+        steps = (_small_tape_steps(S * B, T, method, x0.element_size(), L, H, tape_steps) if grads else None) or _tape_steps(T, method, tape_steps)
         per_traj = hode.capi.tape_nbytes(1, steps, x0.element_size(), L, H)
         cap = max(1, _tape_budget(x0.device, S * B * per_traj) // per_traj) if grads else S * B
         ss = torch.zeros(1, dtype=torch.float64, device=x0.device)
@@ -429,6 +464,10 @@ class HybridODENN(nn.Module):
     def _params_on(self, dev, params: Optional[Dict[str, torch.Tensor]] = None):
         """(nn_flat, ode_vec) on the compute device; `params` optionally overrides named entries
         (`ode_<buf>` / `nn_<name with . -> _>`, hybrid_ode_nn.py:403-420)."""
+        if params is None:
+            fast = self._params_fast(dev)
+            if fast is not None:
+                return fast
         pieces = []
         for name, p in self.nn_residual.named_parameters():
             v = None if params is None else params.get(f"nn_{name.replace('.', '_')}")
@@ -439,6 +478,54 @@ class HybridODENN(nn.Module):
             v = None if params is None else params.get(f"ode_{n}")
             ode.append(torch.as_tensor(getattr(self.ode_core, n) if v is None else v).reshape(()).float().to(dev))
         return nn_flat, torch.stack(ode)
+
+    def _nn_flat_store(self, dev):
+        """One fp32 buffer on `dev` that the ten parameters of nn_residual are VIEWS of (parameters() order = the kernels' layout),
+        or None when they cannot alias it (model kept on another device / in another dtype).  Checked by address at every
+        use and rebuilt when something re-homed the parameters (.to(), .double(), deepcopy, a replaced nn_residual);
+        load_state_dict, optimizers and clip_grad_norm_ write through the views."""
+        params = list(self.nn_residual.parameters())
+        st = self.__dict__.get("_flat_nn")
+        if st is not None:
+            flat, offs = st
+            if (len(offs) == len(params) and flat.device == dev and
+                    all(p.dtype == torch.float32 and p.device == dev and p.data_ptr() == flat.data_ptr() + 4 * o and p.is_contiguous()
+                        for p, o in zip(params, offs))):
+                return flat, params
+        if not params or any(p.dtype != torch.float32 or p.device != dev for p in params):
+            self.__dict__["_flat_nn"] = None
+            return None
+        with torch.no_grad():
+            flat = torch.cat([p.detach().reshape(-1) for p in params]).contiguous()
+            offs, off = [], 0
+            for q in params:
+                q.data = flat[off:off + q.numel()].view(q.shape)
+                offs.append(off)
+                off += q.numel()
+            # weights 1, biases 0: the L2 term of loss() is one masked dot product over the flat vector
+            mask = torch.cat([torch.full((q.numel(),), 1.0 if q.dim() == 2 else 0.0, device=dev) for q in params])
+        self.__dict__["_flat_nn"] = (flat, offs)
+        self.__dict__["_flat_wmask"] = mask
+        return flat, params
+
+    def _params_fast(self, dev):
+        """(nn_flat, ode_vec) without per-step gathers: the parameters alias one flat buffer (_nn_flat_store) and the 17 mechanistic
+        constants are stacked once per change (keyed by the identity and version counter of every buffer: setattr, in-place
+        updates and load_state_dict all show).  ~0.02 ms of host time instead of 0.16 (tools/prof_class_step.py)."""
+        st = self._nn_flat_store(dev)
+        if st is None:
+            return None
+        flat, params = st
+        bufs = [getattr(self.ode_core, n) for n in ODE_PARAM_NAMES]
+        if any((not torch.is_tensor(b)) or b.requires_grad for b in bufs):
+            return None
+        key = tuple((id(b), b._version) for b in bufs)
+        oc = self.__dict__.get("_ode_cache")
+        if oc is None or oc[0] != key or oc[1].device != dev:
+            oc = (key, torch.stack([b.detach().reshape(()).float().to(dev) for b in bufs]))
+            self.__dict__["_ode_cache"] = oc
+        nn_flat = _FlatNN.apply(flat, *params) if torch.is_grad_enabled() and any(p.requires_grad for p in params) else flat
+        return nn_flat, oc[1]
 
     @staticmethod
     def _input(u, key, dev, n):
@@ -523,20 +610,73 @@ class HybridODENN(nn.Module):
         self.last_solve_info = info
         return y
 
-    def _warn_failures(self, info):
-        """Never raise on an integration failure: log and keep the zero rows (hybrid_ode_nn.py:243-256)."""
+    def _ship_indices(self, idx, dev):
+        """The <= 20 physics indices to the device through a small ring of PINNED buffers, asynchronously: a copy from pageable
+        memory makes the host wait for the stream (0.36 ms per step once nothing else stalls the pipeline, tools/prof_class_step.py)."""
+        if dev.type != "cuda" or idx.numel() > 32:
+            return idx.to(dev)
+        ring = self.__dict__.get("_idx_ring")
+        if ring is None:
+            ring = self.__dict__["_idx_ring"] = {"bufs": [torch.empty(32, dtype=torch.int64).pin_memory() for _ in range(4)],
+                                                 "evs": [None] * 4, "i": 0}
+        k = ring["i"]
+        ring["i"] = (k + 1) % 4
+        if ring["evs"][k] is not None:
+            ring["evs"][k].synchronize()              # four steps old: complete
+        buf = ring["bufs"][k][:idx.numel()]
+        buf.copy_(idx)
+        out = buf.to(dev, non_blocking=True)
+        ring["evs"][k] = torch.cuda.Event()
+        ring["evs"][k].record()
+        return out
+
+    def _flush_deferred_warning(self, wait=False):
+        """Look at the worst statuses that have arrived in pinned memory since (all of them when wait=True): each is written into
+        the solve's own info dict as `worst_status`; a non-zero one logs the reference's warnings now."""
+        q = self.__dict__.get("_pending_fail")
+        while q:
+            host, ev, info = q[0]
+            if not wait and len(q) < 4 and not ev.query():
+                break
+            ev.synchronize()
+            q.pop(0)
+            info["worst_status"] = int(host[0])
+            if info["worst_status"] != 0:
+                self._warn_failures(info)
+
+    def _warn_failures(self, info, defer=False):
+        """Never raise on an integration failure: log and keep the zero rows (hybrid_ode_nn.py:243-256).
+        defer=True (the training path, loss()): when the host does not know yet whether anything failed, it does not wait for
+        the device to find out -- the worst status travels to pinned host memory behind the solve and is looked at when a later
+        step arrives here, or when solve_failures() asks: the same warnings, a step or two late, no pipeline stall."""
+        if self.__dict__.get("_pending_fail"):
+            self._flush_deferred_warning()
+        if defer and logger.isEnabledFor(logging.WARNING) and "status" in info and "worst_status" not in info and info["status"].is_cuda:
+            slots = self.__dict__.get("_fail_host")
+            if slots is None:
+                slots = self.__dict__["_fail_host"] = [torch.zeros(1, dtype=torch.int32).pin_memory() for _ in range(4)]
+                self.__dict__["_fail_i"] = 0
+            k = self.__dict__["_fail_i"]
+            self.__dict__["_fail_i"] = (k + 1) % 4
+            slots[k].copy_(info["status"].max().reshape(1), non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self.__dict__.setdefault("_pending_fail", []).append((slots[k], ev, info))
+            return
         if logger.isEnabledFor(logging.WARNING) and "status" in info and info.get("worst_status", 1) != 0:
             bad = torch.nonzero(info["status"]).flatten()
-            if bad.numel():
+            st = info["status"][bad].tolist()
+            info.setdefault("worst_status", max(st) if st else 0)        # (the host has looked now)
+            if st:
                 msgs = {1: "step budget exhausted", 2: "Required step size is less than spacing between numbers.",
                         3: "non-finite state"}
-                st = info["status"][bad].tolist()
                 for b, s in list(zip(bad.tolist(), st))[:8]:
                     logger.warning(f"ODE solver failed for batch {b}: {msgs.get(s, s)}")
 
     def solve_failures(self) -> int:
         """Number of trajectories of the last solve / loss / elbo that did not reach the end of their grid (their rows
         from the failure on are zero, hybrid_ode_nn.py:243-256).  Synchronises with the device."""
+        self._flush_deferred_warning(wait=True)
         st = self.last_solve_info.get("status")
         return 0 if st is None else int((st != 0).sum())
 
@@ -733,7 +873,7 @@ class HybridODENN(nn.Module):
             n = min(20, len(tp))
             idx = torch.randperm(len(tp))[:n]                         # global RNG, same draw as the reference
             idx = idx[idx < tp.shape[-1]]                              # (the reference raises IndexError here)
-            idx_d = idx.to(dev)
+            idx_d = self._ship_indices(idx, dev)
 
         if self.fused_likelihood and self.adjoint and torch.is_grad_enabled():
             # solve + MSE + adjoint piece by piece in one pass (_GaussLikFn): no tape is held until backward() and a
@@ -744,7 +884,7 @@ class HybridODENN(nn.Module):
                                          obs.to(dev, torch.float32).contiguous(), nl.hidden_dim, nl.hip_layers, hode.METHOD_DP54,
                                          1e-6, 1e-8, 1, info, None, True, self.tape_steps)
             self.last_solve_info = info
-            self._warn_failures(info)
+            self._warn_failures(info, defer=True)
             data_loss = (ss / obs.numel()).float()
         else:
             pred = self._solve(x0, tp, u, "dopri5", 1e-6, 1e-8,      # defaults, like reference :291
@@ -775,6 +915,10 @@ class HybridODENN(nn.Module):
         if lambda2 > 0:
             if self.use_variational:
                 reg_loss = bayes_loss(self, obs, noise_sigma=1.0, n_samples=5)
+            elif self.__dict__.get("_flat_nn") is not None and nn_flat.numel() == self.__dict__["_flat_wmask"].numel():
+                # nn_residual.regularization_loss(l2_weight=lambda2) = lambda2 * sum ||W_l||^2 as ONE masked dot product over the flat
+                # vector (the per-layer pow / sum / mul / add chain is twenty launches forward and as many backward)
+                reg_loss = lambda2 * torch.dot(nn_flat * self.__dict__["_flat_wmask"], nn_flat)
             else:
                 reg_loss = self.nn_residual.regularization_loss(l2_weight=lambda2)
                 reg_loss = reg_loss.to(dev) if torch.is_tensor(reg_loss) else torch.tensor(float(reg_loss), device=dev)

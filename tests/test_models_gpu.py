@@ -712,7 +712,9 @@ def test_taped_solve_reports_failures_through_its_one_synchronisation(M, golden_
     with caplog.at_level(logging.WARNING):
         m.zero_grad()
         m.loss(batch, 0.0, 0.0, use_physics_loss=False).backward()
-    assert m.last_solve_info["worst_status"] == 0 and m.solve_failures() == 0
+    # (a tape this small is sized for the no-grad step budget: nothing to retry, so the host does not even wait for the status
+    #  during the step -- the worst status arrives behind it and is read when somebody asks)
+    assert m.solve_failures() == 0 and m.last_solve_info["worst_status"] == 0
     assert not [r for r in caplog.records if "ODE solver failed" in r.getMessage()]
     g_ok = torch.cat([p.grad.reshape(-1) for p in m.nn_residual.parameters()]).clone()
     assert bool(torch.isfinite(g_ok).all()) and float(g_ok.abs().max()) >= 0.0
@@ -725,9 +727,9 @@ def test_taped_solve_reports_failures_through_its_one_synchronisation(M, golden_
         m.zero_grad()
         loss = m.loss(batch_bad, 0.0, 0.0, use_physics_loss=False)
         loss.backward()
+        assert m.solve_failures() == 1                          # (asks: the deferred warning is logged here at the latest)
     st = m.last_solve_info["status"].cpu().numpy()
     assert m.last_solve_info["worst_status"] == int(st.max()) and st[2] != 0 and (np.delete(st, 2) == 0).all()
-    assert m.solve_failures() == 1
     msgs = [r.getMessage() for r in caplog.records if "ODE solver failed" in r.getMessage()]
     assert len(msgs) == 1 and "batch 2" in msgs[0]
     g_bad = torch.cat([p.grad.reshape(-1) for p in m.nn_residual.parameters()])
