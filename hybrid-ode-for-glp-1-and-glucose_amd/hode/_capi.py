@@ -45,6 +45,14 @@ def load():
                 raise HodeError(f"{_SO} was not built from the kernel sources next to it (binary {_build.binary_stamp()}, sources "
                                 f"{_build.source_stamp()}): rebuild with `python __graft_entry__.py` (or `make -C {_build.CSRC}`); "
                                 "HODE_ALLOW_STALE=1 loads it anyway")
+        if os.environ.get("HODE_LIB") and not os.environ.get("HODE_ALLOW_STALE") and os.path.exists(_SO + ".srcsha"):
+            # a development library that carries a source stamp (make lab writes one) must have been built from THESE sources:
+            # the bitwise lab-versus-product tests would otherwise compare against last week's kernels without saying so
+            from . import _build
+            want = _build.lab_source_stamp()
+            if want is not None and os.path.abspath(_SO) == os.path.abspath(_build.LAB_SO) and _build.binary_stamp(_SO) != want:
+                raise HodeError(f"{_SO} is stale (binary {_build.binary_stamp(_SO)}, sources {want}): `make -C {_build.CSRC} lab`; "
+                                "HODE_ALLOW_STALE=1 loads it anyway")
         _lib = C.CDLL(_SO)
         _lib.hode_version.restype = C.c_char_p
         _lib.hode_tape_bytes.restype = C.c_size_t

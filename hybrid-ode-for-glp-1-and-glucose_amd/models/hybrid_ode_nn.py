@@ -71,7 +71,7 @@ class _RhsFn(torch.autograd.Function):
 TAPE_BUDGET_BYTES = 64 << 30
 
 
-_budget_cache: Dict[Tuple[int, int], int] = {}
+_budget_cache: Dict[Tuple[int, int], list] = {}
 _span_cache: Dict[torch.device, torch.Tensor] = {}
 
 
@@ -86,13 +86,16 @@ def _tape_budget(dev, need: int = 0):
     """min(TAPE_BUDGET_BYTES, 80 % of what the allocator can still hand out on this device) -- no synchronisation.
     Asking the allocator costs ~0.25 ms of host time (memory_stats walks a dictionary), as much as a whole small-batch
     solve: a caller that passes the bytes it `need`s gets the last answer back while that is at least 4x the need."""
-    key = (torch.device(dev).index or 0, TAPE_BUDGET_BYTES)
-    if need > 0 and 4 * need <= _budget_cache.get(key, 0):
-        return _budget_cache[key]
+    d = torch.device(dev)
+    key = (d.index if d.index is not None else torch.cuda.current_device(), TAPE_BUDGET_BYTES)
+    hit = _budget_cache.get(key)
+    if need > 0 and hit is not None and 4 * need <= hit[0] and hit[1] > 0:
+        hit[1] -= 1                               # an answer is good for 64 uses: free memory moves (other tensors, a second model)
+        return hit[0]
     free, _ = torch.cuda.mem_get_info(dev)
     reusable = torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)     # cached blocks torch can re-use
-    _budget_cache[key] = max(1, min(TAPE_BUDGET_BYTES, int(0.8 * (free + reusable))))
-    return _budget_cache[key]
+    _budget_cache[key] = [max(1, min(TAPE_BUDGET_BYTES, int(0.8 * (free + reusable)))), 64]
+    return _budget_cache[key][0]
 
 
 # Accepted-step budget of a solve that records a tape: every step costs 6*(L*256 + 32) + 36 B of tape, so the default is

@@ -140,7 +140,9 @@ int hode_solve_fwd_f64(void *stream, int B, int T, const double *x0, const doubl
  *      floating-point atomics -- every workgroup writes one gradient row into the tail of the tape and a second, fixed-order
  *      pass adds the rows: the same call gives the same bits (the reference's CPU training is deterministic).  Generic shapes:
  *      coalesced atomics, reproducible to rounding only.  tape: the buffer the forward filled.  It is not const: the adjoint
- *      uses its tail (the gradient rows) as scratch; what the forward recorded stays intact, the same tape may be walked
+ *      uses its tail (the gradient rows) as scratch -- and its LDS-DMA reads whole 256-byte rows: up to 224 bytes beyond the last stage
+ *      record and up to 224 beyond a step entry, i.e. into the regions that FOLLOW them inside the same buffer (never beyond
+ *      hode_tape_bytes_hl() bytes: the gradient rows, at least 256 bytes, close the buffer) --; what the forward recorded stays intact, the same tape may be walked
  *      again.
  *      nsteps[b], status[b]: what the forward returned for this tape.  The adjoint walks min(nsteps[b], max_steps) steps:
  *      a count larger than the tape it is handed (the caller merged the bookkeeping of a re-integration with a larger

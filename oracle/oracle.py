@@ -12,7 +12,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "_build", "libhode_oracle.so")
+_SO = os.environ.get("HODE_ORACLE_LIB") or os.path.join(_HERE, "_build", "libhode_oracle.so")   # (the sanitizer build: make asan)
 _lib = None
 
 METHOD_DP54 = 0

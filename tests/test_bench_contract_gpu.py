@@ -96,7 +96,8 @@ def test_rccl_backend_one_rank_runs_the_data_parallel_step_and_the_sharded_elbo(
     """The RCCL path itself ("nccl" backend: device-tensor all_reduce of the fp64 message, `elbo(group=...)`'s gradient
     collective) on the one GPU a test box has: a process group of ONE rank.  It cannot show scaling, but it executes
     `dist.init_process_group("nccl", device_id=...)`, the collectives on device buffers and the code around them exactly as an
-    8-rank job does (that path had never run).  Results must be the bits of the same step without a group."""
+    8-rank job does (that path had never run).  Results must be the bits of the same step without a group.
+    Round 4 adds the data side's exchange: GlucoseDataset(group=...)'s all-gather of the window moments (13 doubles per rank)."""
     code = f"""
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, {ROOT!r}); sys.path.insert(0, {os.path.join(ROOT, "hybrid-ode-for-glp-1-and-glucose_amd")!r})
@@ -131,6 +132,17 @@ assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
 p_grp, l_grp = run(2)
 m = vi(); torch.manual_seed(1); e1 = m.elbo(batch, n_samples=3, noise_sigma=1.0, group=True); e1.backward()
 g1 = torch.cat([p_.grad.reshape(-1) for p_ in m.variational_params.means.values()]).clone()
+# the dataset's one exchange step (DESIGN 7): GlucoseDataset(group=...) all-gathers its shard's window moments over RCCL
+import numpy as np, pandas as pd
+from hode.datagen import GlucoseDataset
+tb = np.load({os.path.join(ROOT, "tests", "golden", "g9_4gi_dataset_table.npz")!r}, allow_pickle=False)
+csv = {str(tmp_path / "all.csv")!r}
+pd.DataFrame(tb["table"], columns=list(tb["columns"])).to_csv(csv, index=False, float_format="%.17g")
+d_plain = GlucoseDataset(csv, sequence_length=20, stride=10)
+d_grp = GlucoseDataset(csv, sequence_length=20, stride=10, group=True)
+assert np.array_equal(d_plain.state_mean, d_grp.state_mean) and np.array_equal(d_plain.state_std, d_grp.state_std)
+ia = np.arange(len(d_plain))
+assert torch.equal(d_plain.batch(ia)["observations"], d_grp.batch(ia)["observations"])
 dist.barrier(); torch.cuda.synchronize(); dist.destroy_process_group()
 assert torch.equal(p_plain, p_grp), float((p_plain - p_grp).abs().max())
 assert max(abs(a - b) / abs(a) for a, b in zip(l_plain, l_grp)) < 1e-12

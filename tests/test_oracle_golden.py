@@ -288,3 +288,47 @@ def test_oracle_activations_vs_reference(golden_dir, name, code):
     # the activation really is a different function
     relu = O.rhs(g["x"], g["t"], g["meal"], g["tvns"], None, g["ode"], g["nn_flat"], 16, 3, dtype=np.float64)
     assert rel(relu, g["rhs_f64"]) > 1e-3
+
+
+def test_oracle_under_address_and_ub_sanitizers(golden_dir):
+    """`make -C oracle asan` (gcc -fsanitize=address,undefined): the checker itself is checked -- RHS + VJP, an adaptive solve with
+    a tape, the adjoint, a failing trajectory, the SciPy-mode solve and the 4GI generator run through the instrumented build in a
+    child process (libasan must be the first library of the process) and must come back clean and with the golden values."""
+    import shutil
+    import subprocess
+    import sys
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run(["make", "-C", os.path.join(here, "oracle"), "-s", "asan"], check=True)
+    asan = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    if not os.path.isabs(asan) or not os.path.exists(asan):
+        pytest.skip("libasan not found")
+    code = f"""
+import os, sys, numpy as np
+sys.path.insert(0, {here!r})
+from oracle import oracle as O
+from oracle import fourgi as F
+g = np.load(os.path.join({golden_dir!r}, "g4_t61_pulses.npz")); w = np.load(os.path.join({golden_dir!r}, "g0_weights_h64_l4.npz"))
+for dt in (np.float32, np.float64):
+    f = O.rhs(g["x0"], np.zeros(len(g["x0"])), g["meal"][:, 0], g["tvns"][:, 0], None, w["ode"], w["nn_flat"], 64, 4, dtype=dt)
+    O.rhs_vjp(g["x0"], np.zeros(len(g["x0"])), g["meal"][:, 0], g["tvns"][:, 0], None, w["ode"], w["nn_flat"], 64, 4, np.ones_like(f), dtype=dt)
+    s = O.solve(g["x0"], g["t"], g["meal"], g["tvns"], None, w["ode"], w["nn_flat"], 64, 4, dtype=dt, want_tape=True, max_steps=200)
+    assert int(s.status.max()) == 0
+    gx, gn, go = O.solve_bwd(s, np.ones_like(s.y))
+    assert np.isfinite(gn).all() and np.isfinite(go).all()
+ref = O.solve(g["x0"], g["t"], g["meal"], g["tvns"], None, w["ode"], w["nn_flat"], 64, 4, rtol=1e-10, atol=1e-12, dtype=np.float64)
+assert np.max(np.abs(ref.y - g["y_rk45_tight"]) / (np.abs(g["y_rk45_tight"]) + 1e-3)) < 2e-5
+bad = g["x0"].copy(); bad[1, 3] = -50.0
+with np.errstate(all="ignore"):
+    sb = O.solve(bad, g["t"], g["meal"], g["tvns"], None, w["ode"], w["nn_flat"], 64, 4, dtype=np.float32, want_tape=True, max_steps=8)
+    O.solve_bwd(sb, np.ones_like(sb.y))
+assert sb.status[1] != 0
+O.solve_reference_mode(g["x0"][:2], g["t"], g["meal"][:2], g["tvns"][:2], None, w["ode"], w["nn_flat"], 64, 4)
+F.simulate(F.BASELINE[None] * np.ones((3, 1)), 13, 5.0, [0.2], [60.0])
+print("sanitized oracle ok")
+"""
+    env = dict(os.environ, LD_PRELOAD=asan, HODE_ORACLE_LIB=os.path.join(here, "oracle", "_build", "libhode_oracle_asan.so"),
+               ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "sanitized oracle ok" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
