@@ -526,6 +526,36 @@ __global__ __launch_bounds__(256, 1) void rhs_bwd_kernel(const RhsArgs<R> a)
         if (lane < 6) a.gx[(size_t)s * 6 + lane] = Z;
         if (a.gt && lane == 0) a.gt[s] = gt;
     }
+    // ---- the four waves' accumulators are summed in LDS first (the image of the transposed matrices is dead now) and ONE wave
+    //      flushes: the flush is P atomics per wave on the same 54 KB, and it -- not the arithmetic -- is what the kernel costs.  Round
+    //      3 launched one wave per sample, each flushing its own full gradient: 640 samples of the physics term at the reference's
+    //      batch (32 windows x 20 indices) = 8.6 M same-address atomics, 0.97 ms -- the largest kernel of the class-path step.
+    R *red = wt;                                                     // [(NL-1) * 64 + ES::count + 1][64]
+    constexpr int kHid = ((NL > 1) ? NL - 1 : 0) * kMaxH;
+    __syncthreads();
+    for (int w = 1; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int l = 0; l < ((NL > 1) ? NL - 1 : 0); ++l)
+#pragma unroll
+                for (int k = 0; k < kMaxH; ++k) red[(l * kMaxH + k) * kWave + lane] = gwh[l][k];
+#pragma unroll
+            for (int i = 0; i < ES::count; ++i) red[(kHid + i) * kWave + lane] = E.gacc[i];
+            red[(kHid + ES::count) * kWave + lane] = go;
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int l = 0; l < ((NL > 1) ? NL - 1 : 0); ++l)
+#pragma unroll
+                for (int k = 0; k < kMaxH; ++k) gwh[l][k] += red[(l * kMaxH + k) * kWave + lane];
+#pragma unroll
+            for (int i = 0; i < ES::count; ++i) E.gacc[i] += red[(kHid + i) * kWave + lane];
+            go += red[(kHid + ES::count) * kWave + lane];
+        }
+        __syncthreads();
+    }
+    if (wave != 0) return;
     if (a.gnn) {
         hidden_flush<R, NL>(gwh, a.gnn, a.H, lane);
         edge_flush<R, NL>(E, a.gnn, a.H, lane);
@@ -537,11 +567,17 @@ __global__ __launch_bounds__(256, 1) void rhs_bwd_kernel(const RhsArgs<R> a)
 
 template <typename R, int NL> static int launch_rhs_bwd_nl(hipStream_t s, const RhsArgs<R> &a)
 {
-    int blocks = (a.B + 3) / 4;
+    // sixteen samples per wave before a workgroup is added (a sample is ~3 us of a wave, a workgroup's flush ~1.5 us of contended
+    // atomics for everybody): 640 samples -> 10 workgroups, 81 920 (4 096 windows x 20 indices) -> 256 with 80 samples per wave
+    int blocks = (a.B + 63) / 64;
     if (blocks > 256) blocks = 256;
     if (blocks < 1) return HODE_OK;
     size_t lds = (size_t)(NL > 1 ? NL - 1 : 1) * kMaxH * kMaxH * sizeof(R);
     if (lds < 4 * (size_t)kStageElems * sizeof(R)) lds = 4 * (size_t)kStageElems * sizeof(R);
+    {
+        const size_t red = ((size_t)(NL > 1 ? NL - 1 : 0) * kMaxH + EdgeSlots<NL>::count + 1) * kWave * sizeof(R);   // the workgroup reduction
+        if (lds < red) lds = red;
+    }
     if (a.gode) {
         auto kern = rhs_bwd_kernel<R, NL, true>;
         if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)

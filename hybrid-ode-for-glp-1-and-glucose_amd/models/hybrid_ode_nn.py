@@ -334,6 +334,66 @@ def _pieces(n_sets, G, cap):
     return [(s, s + 1, a, min(a + cap, G)) for s in range(n_sets) for a in range(0, G, cap)]
 
 
+def _gauss_lik_core(need, x0, nn_flat, ode_vec, t, meal, tvns, gd, obs, H, L, method, rtol, atol, S, info, group=None, want_y=False,
+                    tape_steps=None, scale=1.0, ss=None):
+    """Body of _GaussLikFn.forward (also the data term of _TrainLossFn): sum of squares into `ss` (fp64[1]), gradients of
+    scale * sum of squares with respect to (x0, nn_flat, ode_vec) where need[i], trajectories when want_y."""
+    grads = any(need[:3])
+    B, T = x0.shape[0], t.shape[-1]
+    P = nn_flat.numel() // S
+    steps = (_small_tape_steps(S * B, T, method, x0.element_size(), L, H, tape_steps) if grads else None) or _tape_steps(T, method, tape_steps)
+    per_traj = hode.capi.tape_nbytes(1, steps, x0.element_size(), L, H)
+    cap = max(1, _tape_budget(x0.device, S * B * per_traj) // per_traj) if grads else S * B
+    if ss is None:
+        ss = torch.zeros(1, dtype=torch.float64, device=x0.device)
+    pieces = _pieces(S, B, cap)
+    one_piece = len(pieces) == 1
+    gx0 = torch.zeros_like(x0) if need[0] else None
+    gnn = torch.zeros_like(nn_flat) if need[1] and not one_piece else None
+    gode = torch.zeros_like(ode_vec) if need[2] and not one_piece else None
+    tape, stat, nst, nfe, ys, retried, worst = None, [], [], [], [], 0, 0
+    for s0, s1, lo, hi in pieces:
+        m = s1 - s0
+        rep = lambda v: None if v is None else (v[lo:hi].repeat(m, *([1] * (v.dim() - 1))) if m > 1 else v[lo:hi])  # noqa: E731
+        if grads:
+            sol = _solve_taped(rep(x0), t if t.dim() == 1 else rep(t), rep(meal), rep(tvns), rep(gd), ode_vec[17 * s0:17 * s1],
+                               nn_flat[P * s0:P * s1], H, L, method, rtol, atol, m, steps, tape=tape)
+            tape = sol.tape
+            retried += sol.n_retried
+            worst = None if (worst is None or sol.worst is None) else max(worst, sol.worst)
+        else:
+            sol = hode.solve_fwd(rep(x0), t if t.dim() == 1 else rep(t), rep(meal), rep(tvns), rep(gd), ode_vec[17 * s0:17 * s1],
+                                 nn_flat[P * s0:P * s1], H, L, method=method, rtol=rtol, atol=atol, n_sets=m)
+        _, gy = hode.mse_fwd_bwd(sol.y, rep(obs), scale, loss_sum=ss, want_grad=grads)
+        if grads:
+            g0, gn, go = sol.backward(gy, want_gnn=need[1], want_gode=need[2])
+            if gx0 is not None:
+                gx0[lo:hi] += g0.view(m, hi - lo, 6).sum(0)
+            if one_piece:
+                gnn, gode = gn, go                 # (the whole batch in one launch: the adjoint's buffers ARE the result)
+            else:
+                if gn is not None:
+                    gnn[P * s0:P * s1] += gn
+                if go is not None:
+                    gode[17 * s0:17 * s1] += go
+        stat.append(sol.status), nst.append(sol.nsteps), nfe.append(sol.nfev)
+        if want_y:
+            ys.append(sol.y)
+    one = len(stat) == 1
+    info["status"], info["nsteps"], info["nfev"] = (stat[0], nst[0], nfe[0]) if one else (torch.cat(stat), torch.cat(nst), torch.cat(nfe))
+    info["n_budget_retries"] = retried
+    if grads and worst is not None:
+        info["worst_status"] = worst          # the host has already looked (one synchronisation per piece): 0 = nothing failed
+    if group is not None:
+        # patients sharded over the ranks, the SAME S draws everywhere: one all-reduce(sum) of
+        # [per-set MLP grads | per-set ODE grads | sum of squares] makes value and gradient global on every rank
+        _allreduce_sum([v for v in (gnn, gode, ss) if v is not None], None if group is True else group)
+    y = None
+    if want_y:                                     # the trajectories themselves (S = 1), e.g. for the physics points
+        y = ys[0] if len(ys) == 1 else torch.cat(ys)
+    return ss, y, (gx0, gnn, gode)
+
+
 class _GaussLikFn(torch.autograd.Function):
     """sum_{s,b,k,c} (y_s[b,k,c] - obs[b,k,c])^2 over S parameter sets x B patients, in fp64 -- the data term of the ELBO
     (reference inference/vi.py:60-118) -- with its gradient computed IN THE SAME PASS: per piece of the batch, forward
@@ -344,54 +404,9 @@ class _GaussLikFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x0, nn_flat, ode_vec, t, meal, tvns, gd, obs, H, L, method, rtol, atol, S, info, group=None,
                 want_y=False, tape_steps=None):
-        need = ctx.needs_input_grad
-        grads = any(need[:3])
-        B, T = x0.shape[0], t.shape[-1]
-        P = nn_flat.numel() // S
-        steps = (_small_tape_steps(S * B, T, method, x0.element_size(), L, H, tape_steps) if grads else None) or _tape_steps(T, method, tape_steps)
-        per_traj = hode.capi.tape_nbytes(1, steps, x0.element_size(), L, H)
-        cap = max(1, _tape_budget(x0.device, S * B * per_traj) // per_traj) if grads else S * B
-        ss = torch.zeros(1, dtype=torch.float64, device=x0.device)
-        gx0 = torch.zeros_like(x0) if need[0] else None
-        gnn = torch.zeros_like(nn_flat) if need[1] else None
-        gode = torch.zeros_like(ode_vec) if need[2] else None
-        tape, stat, nst, nfe, ys, retried, worst = None, [], [], [], [], 0, 0
-        for s0, s1, lo, hi in _pieces(S, B, cap):
-            m = s1 - s0
-            rep = lambda v: None if v is None else (v[lo:hi].repeat(m, *([1] * (v.dim() - 1))) if m > 1 else v[lo:hi])  # noqa: E731
-            if grads:
-                sol = _solve_taped(rep(x0), t if t.dim() == 1 else rep(t), rep(meal), rep(tvns), rep(gd), ode_vec[17 * s0:17 * s1],
-                                   nn_flat[P * s0:P * s1], H, L, method, rtol, atol, m, steps, tape=tape)
-                tape = sol.tape
-                retried += sol.n_retried
-                worst = None if (worst is None or sol.worst is None) else max(worst, sol.worst)
-            else:
-                sol = hode.solve_fwd(rep(x0), t if t.dim() == 1 else rep(t), rep(meal), rep(tvns), rep(gd), ode_vec[17 * s0:17 * s1],
-                                     nn_flat[P * s0:P * s1], H, L, method=method, rtol=rtol, atol=atol, n_sets=m)
-            _, gy = hode.mse_fwd_bwd(sol.y, rep(obs), 1.0, loss_sum=ss, want_grad=grads)
-            if grads:
-                g0, gn, go = sol.backward(gy, want_gnn=need[1], want_gode=need[2])
-                if gx0 is not None:
-                    gx0[lo:hi] += g0.view(m, hi - lo, 6).sum(0)
-                if gn is not None:
-                    gnn[P * s0:P * s1] += gn
-                if go is not None:
-                    gode[17 * s0:17 * s1] += go
-            stat.append(sol.status), nst.append(sol.nsteps), nfe.append(sol.nfev)
-            if want_y:
-                ys.append(sol.y)
-        one = len(stat) == 1
-        info["status"], info["nsteps"], info["nfev"] = (stat[0], nst[0], nfe[0]) if one else (torch.cat(stat), torch.cat(nst), torch.cat(nfe))
-        info["n_budget_retries"] = retried
-        if grads and worst is not None:
-            info["worst_status"] = worst          # the host has already looked (one synchronisation per piece): 0 = nothing failed
-        if group is not None:
-            # patients sharded over the ranks, the SAME S draws everywhere: one all-reduce(sum) of
-            # [per-set MLP grads | per-set ODE grads | sum of squares] makes value and gradient global on every rank
-            _allreduce_sum([v for v in (gnn, gode, ss) if v is not None], None if group is True else group)
-        ctx.grads = (gx0, gnn, gode)
-        if want_y:                                     # the trajectories themselves (S = 1), e.g. for the physics points
-            y = ys[0] if len(ys) == 1 else torch.cat(ys)
+        ss, y, ctx.grads = _gauss_lik_core(ctx.needs_input_grad, x0, nn_flat, ode_vec, t, meal, tvns, gd, obs, H, L, method, rtol, atol,
+                                           S, info, group, want_y, tape_steps)
+        if want_y:
             ctx.mark_non_differentiable(y)
             return ss[0], y
         return ss[0]
@@ -403,6 +418,82 @@ class _GaussLikFn(torch.autograd.Function):
         ctx.grads = None
         sc = lambda v: None if v is None else (v * g.to(v.dtype))          # noqa: E731
         return (sc(gx0), sc(gnn), sc(gode)) + (None,) * 15
+
+
+_coef_cache: Dict[tuple, Tuple[torch.Tensor, torch.Tensor]] = {}
+
+
+class _TrainLossFn(torch.autograd.Function):
+    """loss() of reference models/hybrid_ode_nn.py:263-351 as ONE autograd node: total = data + lambda1 * physics + lambda2 * reg
+    with the gradient of all three terms with respect to the flat parameter vector computed in the same pass.
+
+        data     forward solve with tape -> residual / cotangent (mse kernel) -> adjoint           (_gauss_lik_core)
+        physics  states at the sampled grid indices -> ONE batched two-point solve (the finite-difference target, no gradient:
+                 the reference's solve is detached) -> f(t, x, u) (K1) -> residual against the target -> VJP (K5)
+        reg      lambda2 * sum ||W||^2 as a masked dot product, gradient added in place
+
+    About thirty launches where the op-by-op graph of the same arithmetic issues a hundred and ten -- at the reference's batch
+    (32 windows x 61 points) the optimisation step is bound by the number of launches on the host AND on the device
+    (tools/prof_class_step.py).  Same terms, same reference quirks (n = min(20, len(time_points)), the (m / n) factor of indices
+    that fall outside the grid, lambda2 applied twice); the three components come back beside the total."""
+
+    @staticmethod
+    def forward(ctx, nn_flat, ode_vec, x0, t, meal, tvns, gd, obs, idx_d, n_draw, lam1, lam2, wmask, H, L, info, tape_steps):
+        need = (False, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        dev = x0.device
+        B, T = x0.shape[0], t.shape[-1]
+        n_el = obs.numel()
+        acc = torch.zeros(3, dtype=torch.float64, device=dev)              # sum of squares (data) | sum of squares (physics) | sum ||W||^2
+        # ---- data: d/d theta of mean((y - obs)^2); the 1 / n_el rides in the cotangent
+        _, y, (_, gnn, gode) = _gauss_lik_core(need, x0, nn_flat, ode_vec, t, meal, tvns, gd, obs, H, L, hode.METHOD_DP54, 1e-6, 1e-8, 1,
+                                               info, None, True, tape_steps, scale=1.0 / n_el, ss=acc[0:1])
+        m = 0 if idx_d is None else int(idx_d.numel())
+        M = B * m
+        if m > 0:
+            # ---- physics: mean over the m sampled indices of MSE((x(0.1) - x) / 0.1, f(t, x, u)), times m / n_draw
+            state = torch.index_select(y, 1, idx_d).reshape(M, 6)                         # patient-major: [b][index]
+            t_true = (torch.index_select(t, 1, idx_d).reshape(M) if t.dim() == 2 else torch.index_select(t, 0, idx_d).repeat(B))
+            pick = lambda v: None if v is None else (torch.index_select(v, 1, idx_d).reshape(M) if v.dim() == 2   # noqa: E731
+                                                     else v.reshape(B, 1).expand(B, m).reshape(M))
+            ms, vs, gs = pick(meal), pick(tvns), pick(gd)
+            nxt = hode.solve_fwd(state, _short_span(dev), ms, vs, gs, ode_vec, nn_flat, H, L, rtol=1e-6, atol=1e-8).y
+            fd = nxt[:, 1, :] - state
+            fd.div_(0.1)
+            f = hode.rhs_fwd(state, t_true, ms, vs, gs, ode_vec, nn_flat, H, L)
+            c_phys = (m / n_draw) / (M * 6)
+            _, gout = hode.mse_fwd_bwd(f, fd, lam1 * c_phys, loss_sum=acc[1:2], want_grad=True)
+            _, _, gnn_p, gode_p = hode.rhs_bwd(state, t_true, ms, vs, gs, ode_vec, nn_flat, H, L, gout, want_gnn=need[1], want_gode=need[2])
+            if gnn is not None:
+                gnn.add_(gnn_p)
+            if gode is not None:
+                gode.add_(gode_p)
+        else:
+            c_phys = 0.0
+        if lam2 > 0:
+            # ---- reg: nn_residual.regularization_loss(l2_weight=lambda2) = lambda2 * sum ||W||^2, and the total takes lambda2 * reg
+            acc[2:3].copy_(torch.dot(nn_flat * wmask, nn_flat).reshape(1))
+            if gnn is not None:
+                gnn.addcmul_(wmask, nn_flat, value=2.0 * lam2 * lam2)
+        key = (dev, n_el, c_phys, lam1, lam2)
+        co = _coef_cache.get(key)
+        if co is None:
+            if len(_coef_cache) > 64:
+                _coef_cache.clear()
+            co = _coef_cache[key] = (torch.tensor([1.0 / n_el, c_phys, lam2], dtype=torch.float64, device=dev),
+                                     torch.tensor([1.0, lam1, lam2], dtype=torch.float64, device=dev))
+        comps = acc * co[0]                                                # data | physics | reg, as last_loss_components reports them
+        total = torch.dot(comps, co[1]).float()
+        ctx.grads = (gnn, gode)
+        ctx.mark_non_differentiable(comps, y)
+        return total, comps, y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g, *_):
+        gnn, gode = ctx.grads
+        ctx.grads = None
+        sc = lambda v: None if v is None else v.mul_(g.to(v.dtype))        # noqa: E731  (the buffers are this node's own)
+        return (sc(gnn), sc(gode)) + (None,) * 15
 
 
 class HybridODENN(nn.Module):
@@ -877,6 +968,24 @@ class HybridODENN(nn.Module):
             idx = torch.randperm(len(tp))[:n]                         # global RNG, same draw as the reference
             idx = idx[idx < tp.shape[-1]]                              # (the reference raises IndexError here)
             idx_d = self._ship_indices(idx, dev)
+
+        fused_all = (self.fused_likelihood and self.adjoint and torch.is_grad_enabled() and nn_flat.requires_grad
+                     and self.__dict__.get("_flat_nn") is not None and not (lambda2 > 0 and self.use_variational))
+        if fused_all:
+            # the whole loss and its gradient as one autograd node (_TrainLossFn)
+            xs, tt, ins = self._prep_inputs(x0, tp, u, dev)
+            info, nl = {}, self.nn_residual
+            total, comps, pred = _TrainLossFn.apply(nn_flat, ode_vec, xs, tt, ins["meal"], ins["tVNS"], ins["GD"],
+                                                    obs.to(dev, torch.float32).contiguous(), idx_d if idx is not None else None,
+                                                    (min(20, len(tp)) if idx is not None else 1), float(lambda1) if idx is not None else 0.0,
+                                                    float(lambda2), self.__dict__["_flat_wmask"], nl.hidden_dim, nl.hip_layers, info,
+                                                    self.tape_steps)
+            self.last_solve_info = info
+            self._warn_failures(info, defer=True)
+            self.last_loss_components = (comps[0], comps[1], comps[2])
+            if logger.isEnabledFor(logging.DEBUG):
+                logger.debug(f"Loss components - Data: {float(comps[0]):.4f}, Physics: {float(comps[1]):.4f}, Reg: {float(comps[2]):.4f}")
+            return total.to(self.device)
 
         if self.fused_likelihood and self.adjoint and torch.is_grad_enabled():
             # solve + MSE + adjoint piece by piece in one pass (_GaussLikFn): no tape is held until backward() and a
