@@ -34,6 +34,12 @@
 
 namespace hode {
 
+// 1: the propagation waves read the lane's 16-lane row of delta back from the hand-off slot (four 16-byte broadcast reads) and take
+//    the operands of the packed FMAs from there (ws_wt_group_lb); 0: round 3's form, one v_mov_b32_dpp row_ror:n per rotation
+#ifndef HODE_WS_PROP_LB
+#define HODE_WS_PROP_LB 1
+#endif
+
 namespace {
 
 constexpr int kWsP = 8;                                    // propagation waves per workgroup
@@ -59,7 +65,7 @@ template <int NL> constexpr int ws_hand_elems() { return (NL + 1) * kWave; }    
 template <int NL, int U> constexpr size_t ws_lds_elems()
 {
     return (size_t)(NL - 1) * kMaxH * kMaxH + 8 * kWave + (size_t)kWsP * U * kWsRing * ws_rec_elems<NL>() +
-           (size_t)kWsP * U * 2 * ws_hand_elems<NL>() + 2 * 16 + 16 + (size_t)kWsP * U * 2 * kWave;
+           (size_t)kWsP * U * 2 * ws_hand_elems<NL>() + 2 * 16 + 16 + (size_t)kWsP * U * 2 * kWave + 32 + 6 * kWave;
 }
 
 // J_mech^T kb as mech_vjp (hode_device.h) computes it, with the five terms evaluated on ALL lanes and selected by lane -- the
@@ -104,7 +110,11 @@ __device__ __forceinline__ void wt_blk_store(float *__restrict__ wt, const float
         for (int e = tid; e < kMaxH * kMaxH; e += nthreads) {
             const int w = ((e & 1) << 1) | ((e >> 1) & 1), lane = (e >> 2) & 63, n = e >> 8;      // word = { w0, w2, w1, w3 }: the pairs (a0, a2), (a1, a3)
             const int i = lane & 15, r = lane >> 4;
+#if HODE_WS_PROP_LB
+            const int row = 16 * r + n, col = 16 * w + i;                                          // natural column order (ws_wt_group_lb)
+#else
             const int row = 16 * r + ((i - n) & 15), col = 16 * w + i;
+#endif
             wt[(size_t)l * kMaxH * kMaxH + e] = (row < H && col < H) ? Wl[(size_t)row * H + col] : 0.f;
         }
         Wl += (size_t)H * H + H;
@@ -141,6 +151,108 @@ template <int G> __device__ __forceinline__ void ws_wt_group(const Vec4<float> (
     }
 #undef HODE_WS_STEP
 }
+// Columns 4 G .. 4 G + 3 (the words w[0..3]: {W_l[16 r + c][16 w + i] : w}, natural column order) of one matrix for one trajectory;
+// q = delta[16 r + 4 G .. + 3], the quarter of the lane's row that the wave read back from the hand-off slot: the packed FMAs pick
+// the low / high half of a loaded register pair (op_sel) -- no cross-lane instruction.  15 v_mov_b32_dpp fewer per matrix and
+// trajectory than ws_wt_group; same products per accumulator in column order instead of rotation order.
+typedef float ws_f4_t __attribute__((ext_vector_type(4)));
+template <int G> __device__ __forceinline__ void ws_wt_group_lb(const Vec4<float> (&w)[4], const ws_f4_t q, f2_t &a01, f2_t &a23)
+{
+    const f2_t q01 = {q.x, q.y}, q23 = {q.z, q.w};
+#define HODE_WS_LO(I, Q)                                                                                                        \
+    {                                                                                                                           \
+        const f2_t w01 = {w[I].v[0], w[I].v[1]}, w23 = {w[I].v[2], w[I].v[3]};                                                  \
+        asm("v_pk_fma_f32 %0, %2, %4, %0 op_sel_hi:[1,0,1]\n\tv_pk_fma_f32 %1, %3, %4, %1 op_sel_hi:[1,0,1]"                   \
+            : "+v"(a01), "+v"(a23) : "v"(w01), "v"(w23), "v"(Q));                                                               \
+    }
+#define HODE_WS_HI(I, Q)                                                                                                        \
+    {                                                                                                                           \
+        const f2_t w01 = {w[I].v[0], w[I].v[1]}, w23 = {w[I].v[2], w[I].v[3]};                                                  \
+        asm("v_pk_fma_f32 %0, %2, %4, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\tv_pk_fma_f32 %1, %3, %4, %1 op_sel:[0,1,0] op_sel_hi:[1,1,1]" \
+            : "+v"(a01), "+v"(a23) : "v"(w01), "v"(w23), "v"(Q));                                                               \
+    }
+    if constexpr (G == 0) {
+        const f2_t w01 = {w[0].v[0], w[0].v[1]}, w23 = {w[0].v[2], w[0].v[3]};
+        asm("v_pk_mul_f32 %0, %2, %4 op_sel_hi:[1,0]\n\tv_pk_mul_f32 %1, %3, %4 op_sel_hi:[1,0]" : "=&v"(a01), "=&v"(a23) : "v"(w01), "v"(w23), "v"(q01));
+    } else {
+        HODE_WS_LO(0, q01)
+    }
+    HODE_WS_HI(1, q01) HODE_WS_LO(2, q23) HODE_WS_HI(3, q23)
+#undef HODE_WS_LO
+#undef HODE_WS_HI
+}
+// one 16-byte LDS read as asm: hipcc puts an s_waitcnt vmcnt(0) in front of every LDS read it can see that may alias a pending
+// LDS-DMA (the next record, issued at the top of the iteration), and the hand-off slots sit in the same allocation
+// (the value stays in the ONE register tuple the instruction writes until ws_lds_wait has run: any copy hipcc makes of it before
+//  that -- e.g. to repack it into a struct -- would read registers the LDS has not written yet)
+__device__ __forceinline__ ws_f4_t ws_lds_read128(unsigned addr)
+{
+    ws_f4_t v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+    return v;
+}
+__device__ __forceinline__ void ws_lds_wait(ws_f4_t &a, ws_f4_t &b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void ws_lds_wait(ws_f4_t &a) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a)); }
+// ... with N younger LDS operations allowed to stay in flight (a wave's LDS operations complete in issue order)
+template <int N> __device__ __forceinline__ void ws_lds_wait_n(ws_f4_t &a, ws_f4_t &b)
+{
+    static_assert(N >= 0 && N <= 15, "lgkmcnt is a 4-bit counter");
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N));
+}
+template <int N> __device__ __forceinline__ void ws_lds_wait_n(ws_f4_t &a) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "n"(N)); }
+// `drow[u]`: LDS byte address of delta_{l+1}[16 r] of trajectory u (the lane's row of the vector the wave has just written to its
+// hand-off slot: LDS operations of one wave complete in order).  Quarters are read one group ahead, the weight words two, as before.
+template <int U>
+__device__ __forceinline__ void ws_wt_mul_lb(const float *__restrict__ wt, const float *__restrict__ wt_next, int lane, const unsigned (&drow)[U],
+                                             float (&out)[U], Vec4<float> (&w0)[4], Vec4<float> (&w1)[4])
+{
+    static_assert(U == 1 || U == 2, "");
+    const Vec4<float> *wt4 = reinterpret_cast<const Vec4<float> *>(wt), *nx4 = reinterpret_cast<const Vec4<float> *>(wt_next);
+    f2_t a01[U], a23[U];
+    ws_f4_t qa[U], qb[U];
+    auto wait_all = [](ws_f4_t (&q)[U]) { if constexpr (U == 2) ws_lds_wait(q[0], q[1]); else ws_lds_wait(q[0]); };
+    // what is issued BEHIND a quarter and may stay in flight when it is used: four weight words (+ the U quarter reads behind them)
+    auto wait_behind_w_q = [](ws_f4_t (&q)[U]) { if constexpr (U == 2) ws_lds_wait_n<4 + U>(q[0], q[1]); else ws_lds_wait_n<4 + U>(q[0]); };
+    auto wait_behind_w = [](ws_f4_t (&q)[U]) { if constexpr (U == 2) ws_lds_wait_n<4>(q[0], q[1]); else ws_lds_wait_n<4>(q[0]); };
+#pragma unroll
+    for (int u = 0; u < U; ++u) qa[u] = ws_lds_read128(drow[u]);
+#pragma unroll
+    for (int u = 0; u < U; ++u) qb[u] = ws_lds_read128(drow[u] + 16);
+    wait_all(qa);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < U; ++u) ws_wt_group_lb<0>(w0, qa[u], a01[u], a23[u]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w0[i] = wt4[(8 + i) * kMaxH + lane];
+#pragma unroll
+    for (int u = 0; u < U; ++u) qa[u] = ws_lds_read128(drow[u] + 32);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < U; ++u) ws_wt_group_lb<1>(w1, qb[u], a01[u], a23[u]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w1[i] = wt4[(12 + i) * kMaxH + lane];
+#pragma unroll
+    for (int u = 0; u < U; ++u) qb[u] = ws_lds_read128(drow[u] + 48);
+    wait_behind_w_q(qa);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < U; ++u) ws_wt_group_lb<2>(w0, qa[u], a01[u], a23[u]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w0[i] = nx4[(0 + i) * kMaxH + lane];
+    wait_behind_w(qb);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < U; ++u) ws_wt_group_lb<3>(w1, qb[u], a01[u], a23[u]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w1[i] = nx4[(4 + i) * kMaxH + lane];
+#pragma unroll
+    for (int u = 0; u < U; ++u) out[u] = blk_rows_finish<false, false>(a01[u], a23[u], 0.f);
+}
+
 // the four accumulators -> (W^T delta)[unit of the lane]: hode_device.h blk_rows_finish (pairs (a0, a2), (a1, a3); no bias)
 __device__ __forceinline__ float ws_wt_finish(const f2_t a02, const f2_t a13) { return blk_rows_finish<false, false>(a02, a13, 0.f); }
 // The sixteen 16-byte reads of a matrix are issued ahead of their use: on entry w0 / w1 hold the words of groups 0 and 1 (loaded
@@ -339,6 +451,8 @@ __global__ __launch_bounds__(64 * kWsWaves) void solve_bwd_ws_kernel(const AdjAr
     // dependent HBM round trips, 4 000-6 000 cycles in every sixth iteration with all sixteen waves of the workgroup waiting at the
     // barrier (tools/ws_trace.py) -- and kept the step constants in twelve VGPRs that pushed the loop into scratch.
     R *hdrs = reinterpret_cast<R *>(niter + 16);
+    R *odeL = hdrs + (size_t)NT * 2 * kWave;               // [20] the 17 mechanistic constants of this parameter set (+ padding)
+    R *w5L = odeL + 32;                                    // [6][64] output-layer weights, Wout[q][unit of the lane] (0 beyond H)
 
     const int lane = threadIdx.x & 63;
     const int c8 = lane & 7, grp = lane >> 3;
@@ -366,6 +480,11 @@ __global__ __launch_bounds__(64 * kWsWaves) void solve_bwd_ws_kernel(const AdjAr
     tableau_rowsT_store<R>(rowsT, method, threadIdx.x, 64 * kWsWaves);
     if (threadIdx.x < 2 * 16) tags[threadIdx.x] = 0;
     if (threadIdx.x == 0) *niter = 0;
+    if (threadIdx.x < 20) odeL[threadIdx.x] = threadIdx.x < 17 ? a.ode_p[17 * set + threadIdx.x] : R(0);
+    if (threadIdx.x < 6 * kWave) {
+        const int q = threadIdx.x >> 6, j = threadIdx.x & 63;
+        w5L[threadIdx.x] = j < a.H ? nn_set[9 * a.H + a.H + (size_t)NM * ((size_t)a.H * a.H + a.H) + q * a.H + j] : R(0);
+    }
     __syncthreads();
     // iterations = the longest slot's number of stages (+ 1: accumulation runs one iteration behind).  Slot t = U wave + u takes
     // the trajectories t, t + NT, ... of this workgroup's share (slot-major, like the one-role kernel's wave-major deal)
@@ -398,19 +517,13 @@ __global__ __launch_bounds__(64 * kWsWaves) void solve_bwd_ws_kernel(const AdjAr
         //  lighter -- the SIMD's arbiter already prefers the older waves, and these are the workgroup's first eight; lab switch 16 sets it)
         if (dbg & 16) __builtin_amdgcn_s_setprio(2);
         // edge weights in registers (no accumulators here: there is room); per trajectory: step / stage cursors
-        R w1r[8], w5[6];
-        OdeP<R> o;
+        R w1r[8];
         R lam[U], ZZ[U];
         int hp[U];                                        // which of the slot's two header buffers holds the CURRENT step
         int bi_next[U], b[U], n[U], st[U], s[U], knext[U], k[U], cur[U];
         bool active[U], ok[U];
         const R *__restrict__ stg[U];
         {
-            const R live = (lane < a.H) ? 1.f : 0.f;
-            const int j = (lane < a.H) ? lane : a.H - 1;
-            const R *pout = nn_set + 9 * a.H + a.H + (size_t)NM * ((size_t)a.H * a.H + a.H);
-#pragma unroll
-            for (int q = 0; q < 6; ++q) w5[q] = live * pout[q * a.H + j];
             // first-layer weights of the six state inputs in the rotating order of out_rot (hode_device.h): lane (r, i) keeps, for
             // input o = i & 7, w1r[n] = W1[16 r + ((i - n) & 15)][1 + o] (GLP1, o = 3, feeds inputs 4 and 7; zero for o >= 6), so
             // that the state cotangent W1^T delta_1 is 8 FMAs on delta_1 in its natural layout + a 7-instruction reduction that
@@ -426,11 +539,6 @@ __global__ __launch_bounds__(64 * kWsWaves) void solve_bwd_ws_kernel(const AdjAr
                 if (oo == 3) v += nn_set[kk * 9 + 7];
                 w1r[n_] = okw ? v : 0.f;
             }
-            ode_load(o, a.ode_p + 17 * set);
-            // as VGPRs: 17 wave-uniform SGPRs are more than this loop has (they were spilled to lanes of a VGPR and read back with
-            // a v_readlane per use), and a VALU instruction reads one SGPR only -- the state / cotangent broadcasts are SGPRs already
-            asm volatile("" : "+v"(o.a_GI), "+v"(o.k_I), "+v"(o.rho), "+v"(o.G_b), "+v"(o.I_b), "+v"(o.E_max), "+v"(o.EC_50), "+v"(o.Glu_b));
-            asm volatile("" : "+v"(o.V_max), "+v"(o.K_m), "+v"(o.k_L), "+v"(o.k_GE0), "+v"(o.IGD_50), "+v"(o.g), "+v"(o.p_7), "+v"(o.p_8), "+v"(o.p_9));
         }
         auto rec_of = [&](int u) -> R * { return recs + (size_t)(wave * U + u) * kWsRing * kRec; };
         auto hand_of = [&](int u, int par) -> R * { return hands + ((size_t)(wave * U + u) * 2 + par) * kHand; };
@@ -570,6 +678,30 @@ __global__ __launch_bounds__(64 * kWsWaves) void solve_bwd_ws_kernel(const AdjAr
             //      mechanistic part, then the cotangent through the layers; every delta goes to the hand-off slot
             R hact[U][NL], kb[U], ts[U], tv[U], mech[U], d[U];
             R *__restrict__ hd[U];
+            // the 17 mechanistic constants: five broadcast reads per iteration into VGPRs that live through the mechanistic part only
+            // (as VGPRs because 17 wave-uniform SGPRs are more than this loop has and a VALU instruction reads one SGPR only; held for
+            // the whole loop they were 17 of the 128 registers the matrices' operands now need -- asm: see ws_lds_read128)
+            OdeP<R> o;
+            {
+                const unsigned oa = (unsigned)(size_t)(__attribute__((address_space(3))) R *)odeL;
+                ws_f4_t c0 = ws_lds_read128(oa), c1 = ws_lds_read128(oa + 16), c2 = ws_lds_read128(oa + 32), c3 = ws_lds_read128(oa + 48),
+                        c4 = ws_lds_read128(oa + 64);
+                ws_lds_wait(c0, c1);
+                ws_lds_wait(c2, c3);
+                ws_lds_wait(c4);
+                o.a_GI = c0.x; o.k_I = c0.y; o.rho = c0.z; o.G_b = c0.w; o.I_b = c1.x; o.E_max = c1.y; o.EC_50 = c1.z;
+                o.Glu_b = c1.w; o.V_max = c2.x; o.K_m = c2.y; o.k_L = c2.z; o.k_GE0 = c2.w; o.IGD_50 = c3.x; o.g = c3.y;
+                o.p_7 = c3.z; o.p_8 = c3.w; o.p_9 = c4.x;
+            }
+            // ... and the lane's six output-layer weights (one table for the workgroup, six 4-byte reads per iteration)
+            R w5[6];
+            {
+                const unsigned wa = (unsigned)(size_t)(__attribute__((address_space(3))) R *)(w5L + lane);
+                asm volatile("ds_read_b32 %0, %6\n\tds_read_b32 %1, %6 offset:256\n\tds_read_b32 %2, %6 offset:512\n\t"
+                             "ds_read_b32 %3, %6 offset:768\n\tds_read_b32 %4, %6 offset:1024\n\tds_read_b32 %5, %6 offset:1280\n\t"
+                             "s_waitcnt lgkmcnt(0)"
+                             : "=&v"(w5[0]), "=&v"(w5[1]), "=&v"(w5[2]), "=&v"(w5[3]), "=&v"(w5[4]), "=&v"(w5[5]) : "v"(wa));
+            }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 hd[u] = hand_of(u, par);
@@ -625,7 +757,14 @@ __global__ __launch_bounds__(64 * kWsWaves) void solve_bwd_ws_kernel(const AdjAr
                     for (int u = 0; u < U; ++u) dp[u] = d[u] * 0.5f;
                 } else {
                     // (the matrix after this one: l - 2, or -- behind the last -- the first matrix of the next stage)
+#if HODE_WS_PROP_LB
+                    unsigned drow[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) drow[u] = (unsigned)(size_t)(__attribute__((address_space(3))) R *)(hd[u] + l * kWave + (lane & 48));
+                    ws_wt_mul_lb<U>(wt + (size_t)(l - 1) * kMaxH * kMaxH, wt + (size_t)(l >= 2 ? l - 2 : NM - 1) * kMaxH * kMaxH, lane, drow, dp, wq0, wq1);
+#else
                     ws_wt_mul<U>(wt + (size_t)(l - 1) * kMaxH * kMaxH, wt + (size_t)(l >= 2 ? l - 2 : NM - 1) * kMaxH * kMaxH, lane, d, dp, wq0, wq1);
+#endif
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
