@@ -89,7 +89,7 @@ int solve_bwd(void *stream, int B, int T, const R *t, int t_batched, const R *me
     a.tape_stage = (const R *)((const char *)tape + tape_stage_offset(B, max_steps, sizeof(R)));
     a.gy = gy; a.gx0 = gx0; a.gnn = gnn; a.gode = gode;
     a.tape_delta = has_delta_tape(sizeof(R), H, L) ? (R *)((char *)tape + tape_delta_offset(B, max_steps, sizeof(R), H, L)) : nullptr;
-    a.partials = tuned_shape(H, L) ? (R *)((char *)tape + tape_partials_offset(B, max_steps, sizeof(R), H, L)) : nullptr;
+    a.partials = (tuned_shape(H, L) || sizeof(R) == 4) ? (R *)((char *)tape + tape_partials_offset(B, max_steps, sizeof(R), H, L)) : nullptr;
     a.partial_rows = adj_partial_rows(B);
     a.act = act_of(L);
     if (!tuned_shape(H, L)) return launch_solve_bwd_generic<R>((hipStream_t)stream, a, layers_of(L), method);

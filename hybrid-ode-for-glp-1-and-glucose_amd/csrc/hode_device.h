@@ -705,7 +705,11 @@ template <typename R, int NL> struct MlpActs {
 // has no register to hold four rows until the end of the evaluation
 template <typename R> struct ActsToRecord {
     R *__restrict__ dst;                  // record + lane
+#ifdef HODE_TAPE_NT
+    __device__ __forceinline__ void put(int l, R v) { __builtin_nontemporal_store(v, dst + l * kWave); }   // write-once stream: nt policy
+#else
     __device__ __forceinline__ void put(int l, R v) { dst[l * kWave] = v; }
+#endif
 };
 
 // x_K of the replicated state layout on every lane.  fp32: a DPP row broadcast into a VGPR (lane K of each 16-lane row holds

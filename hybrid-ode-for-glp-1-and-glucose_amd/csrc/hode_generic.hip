@@ -383,9 +383,15 @@ template <int RPW> struct TeamAccT {
 #pragma unroll
         for (int u = 0; u < 6; ++u) e[u][0] = e[u][1] = 0.f;
     }
-    // one atomic per entry and WORKGROUP for this wave's edge piece
-    __device__ __forceinline__ void flush_edge(const StreamNet<float> &n, float *__restrict__ g, int part, int lane)
+    // ST: the workgroup owns g (its gradient ROW, solve_bwd_generic_kernel): plain stores, no atomics
+    template <bool ST> static __device__ __forceinline__ void emit(float *p, float v)
     {
+        if constexpr (ST) *p = v; else atomic_add(p, v);
+    }
+    // one atomic per entry and WORKGROUP for this wave's edge piece
+    template <bool ST> __device__ __forceinline__ void flush_edge(const StreamNet<float> &n, float *__restrict__ g, int part, int lane)
+    {
+#define atomic_add emit<ST>
         const int H = n.H;
         const bool vA = lane < H, vB = lane + 64 < H;
         if (part == kEdgeOut) {
@@ -414,6 +420,7 @@ template <int RPW> struct TeamAccT {
             if (vA) atomic_add(gb + lane, e[0][0]);
             if (vB) atomic_add(gb + lane + 64, e[0][1]);
         }
+#undef atomic_add
     }
     // accumulators of the matrix at compile-time position SLOT (0 = the LAST hidden matrix, see rhs_vjp_stream), row u of this wave
     template <int SLOT> __device__ __forceinline__ void fma(int u, float dj, float inA, float inB)
@@ -423,27 +430,27 @@ template <int RPW> struct TeamAccT {
         m[u][0] = __builtin_fmaf(dj, inA, m[u][0]);
         m[u][1] = __builtin_fmaf(dj, inB, m[u][1]);
     }
-    __device__ __forceinline__ void flush_one(const float (&m)[RPW][2], float *__restrict__ gW, int H, int j0, int lane)
+    template <bool ST> __device__ __forceinline__ void flush_one(const float (&m)[RPW][2], float *__restrict__ gW, int H, int j0, int lane)
     {
 #pragma unroll
         for (int u = 0; u < RPW; ++u) {
             const int j = j0 + u;
             if (j < H) {
-                if (lane < H) atomic_add(gW + (size_t)j * H + lane, m[u][0]);
-                if (lane + 64 < H) atomic_add(gW + (size_t)j * H + lane + 64, m[u][1]);
+                if (lane < H) emit<ST>(gW + (size_t)j * H + lane, m[u][0]);
+                if (lane + 64 < H) emit<ST>(gW + (size_t)j * H + lane + 64, m[u][1]);
             }
         }
     }
     // one atomic per entry and WORKGROUP (after all its trajectories of a parameter set)
-    __device__ __forceinline__ void flush(const StreamNet<float> &n, float *__restrict__ g, int j0, int lane, int part)
+    template <bool ST = false> __device__ __forceinline__ void flush(const StreamNet<float> &n, float *__restrict__ g, int j0, int lane, int part)
     {
         if (g == nullptr) return;
-        flush_edge(n, g, part, lane);
+        flush_edge<ST>(n, g, part, lane);
         const int nm = n.L - 1;                            // slot i holds hidden matrix nm - 1 - i
-        if (nm > 0) flush_one(m0, g + n.hid_off(nm - 1), n.H, j0, lane);
-        if (nm > 1) flush_one(m1, g + n.hid_off(nm - 2), n.H, j0, lane);
-        if (nm > 2) flush_one(m2, g + n.hid_off(nm - 3), n.H, j0, lane);
-        if (nm > 3) flush_one(m3, g + n.hid_off(nm - 4), n.H, j0, lane);
+        if (nm > 0) flush_one<ST>(m0, g + n.hid_off(nm - 1), n.H, j0, lane);
+        if (nm > 1) flush_one<ST>(m1, g + n.hid_off(nm - 2), n.H, j0, lane);
+        if (nm > 2) flush_one<ST>(m2, g + n.hid_off(nm - 3), n.H, j0, lane);
+        if (nm > 3) flush_one<ST>(m3, g + n.hid_off(nm - 4), n.H, j0, lane);
     }
 };
 
@@ -783,7 +790,7 @@ template <typename R> int launch_solve_fwd_generic(hipStream_t s, const SolveArg
 // register accumulators (TeamAccT), else gradients leave through atomics inside rhs_vjp_stream (fp64, more than four hidden
 // matrices, no parameter gradient wanted).
 template <typename R, bool GODE, bool GD, int kGenTeam, int ACCREG>      // ACCREG: accumulator rows per wave (8 / 16), 0 = atomics
-__global__ __launch_bounds__(64 * kGenTeam) void solve_bwd_generic_kernel(const AdjArgs<R> a, const int method, const int L)
+__global__ __launch_bounds__(64 * kGenTeam) void solve_bwd_generic_kernel(const AdjArgs<R> a, const int method, const int L, const int rows_grid)
 {
     using Acc = std::conditional_t<ACCREG != 0, TeamAccT<ACCREG ? ACCREG : 8>, NoAcc>;
     Acc acc;
@@ -806,7 +813,21 @@ __global__ __launch_bounds__(64 * kGenTeam) void solve_bwd_generic_kernel(const 
     constexpr bool use_gd = GD;
     const int rows_per_k = (((a.H + kGenTeam - 1) / kGenTeam) + 7) & ~7;
     const int j0_k = (part * rows_per_k < a.H) ? part * rows_per_k : a.H;
-    for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+    // ROWS mode (a 2-D grid: blockIdx.y = parameter set, register accumulators, a partials area): the workgroup serves trajectories
+    // of ONE set and leaves its gradient as ONE row of a.partials with plain stores; adj_reduce_kernel adds the rows of a set in
+    // workgroup order -- no floating-point atomics, the same bits run to run (the tuned path's scheme, round 4 for these shapes).
+    const bool rows_mode = ACCREG != 0 && rows_grid != 0;
+    R go_sum = R(0);
+    R *__restrict__ prow = nullptr;
+    if (rows_mode) {
+        const size_t rowlen = adj_partial_rowlen(a.P);
+        prow = a.partials + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * rowlen;
+        for (size_t i = threadIdx.x; i < rowlen; i += 64 * kGenTeam) prow[i] = R(0);
+        __syncthreads();
+    }
+    const int b_first = rows_mode ? (int)blockIdx.y * per_set + (int)blockIdx.x : (int)blockIdx.x;
+    const int b_end = rows_mode ? ((int)blockIdx.y + 1) * per_set : a.B;
+    for (int b = b_first; b < b_end; b += gridDim.x) {
         const int set = b / per_set;
         const StreamNet<R> n{a.nn_p + (size_t)set * a.P, a.H, L, a.act};
         R *__restrict__ g = a.gnn ? a.gnn + (size_t)set * a.P : nullptr;
@@ -879,12 +900,20 @@ __global__ __launch_bounds__(64 * kGenTeam) void solve_bwd_generic_kernel(const 
         if (part == 0) {
             if (lane < 6) a.gx0[(size_t)b * 6 + lane] = lam;
             if constexpr (GODE) {
-                if (a.gode && lane < 17) atomic_add(a.gode + 17 * set + lane, go);
+                if (rows_mode) go_sum += go;
+                else if (a.gode && lane < 17) atomic_add(a.gode + 17 * set + lane, go);
             }
         }
     }
     if constexpr (ACCREG != 0) {
-        if (acc_set >= 0) acc.flush(StreamNet<R>{a.nn_p + (size_t)acc_set * a.P, a.H, L, a.act}, a.gnn ? a.gnn + (size_t)acc_set * a.P : nullptr, j0_k, lane, part);
+        if (rows_mode) {
+            if (acc_set >= 0) acc.template flush<true>(StreamNet<R>{a.nn_p + (size_t)acc_set * a.P, a.H, L, a.act}, prow, j0_k, lane, part);
+            if constexpr (GODE) {
+                if (part == 0 && lane < 17) prow[a.P + lane] = go_sum;
+            }
+        } else if (acc_set >= 0) {
+            acc.flush(StreamNet<R>{a.nn_p + (size_t)acc_set * a.P, a.H, L, a.act}, a.gnn ? a.gnn + (size_t)acc_set * a.P : nullptr, j0_k, lane, part);
+        }
     }
 }
 
@@ -893,14 +922,32 @@ template <typename R, int NW, int ACCREG> static int launch_bwd_generic_t(hipStr
     // with register accumulators a workgroup flushes once: fewer, longer-lived workgroups (a few per CU) beat one per trajectory
     int blocks = a.B < 4096 ? a.B : 4096;
     if (ACCREG && blocks > 1024) blocks = 1024;
-    const dim3 grid(blocks), block(64 * NW);
+    dim3 grid(blocks);
+    const dim3 block(64 * NW);
+    // gradient rows instead of atomics (fp32 register accumulators, enough rows for one workgroup per set at least)
+    const int per_set = a.B / a.n_sets;
+    int bps = 0;
+    if constexpr (ACCREG != 0 && sizeof(R) == 4) {
+        if (a.partials != nullptr && a.gnn != nullptr && a.n_sets <= a.partial_rows && a.n_sets <= 65535) {
+            bps = a.partial_rows / a.n_sets;
+            if (bps > per_set) bps = per_set;
+            if (bps > 1024) bps = 1024;
+            if (bps < 1) bps = 1;
+            grid = dim3(bps, a.n_sets);
+        }
+    }
     const bool gd = a.gd_mode != 0;
     if (a.gode) {
-        if (gd) hipLaunchKernelGGL((solve_bwd_generic_kernel<R, true, true, NW, ACCREG>), grid, block, 0, s, a, method, L);
-        else hipLaunchKernelGGL((solve_bwd_generic_kernel<R, true, false, NW, ACCREG>), grid, block, 0, s, a, method, L);
+        if (gd) hipLaunchKernelGGL((solve_bwd_generic_kernel<R, true, true, NW, ACCREG>), grid, block, 0, s, a, method, L, bps > 0 ? 1 : 0);
+        else hipLaunchKernelGGL((solve_bwd_generic_kernel<R, true, false, NW, ACCREG>), grid, block, 0, s, a, method, L, bps > 0 ? 1 : 0);
     } else {
-        if (gd) hipLaunchKernelGGL((solve_bwd_generic_kernel<R, false, true, NW, ACCREG>), grid, block, 0, s, a, method, L);
-        else hipLaunchKernelGGL((solve_bwd_generic_kernel<R, false, false, NW, ACCREG>), grid, block, 0, s, a, method, L);
+        if (gd) hipLaunchKernelGGL((solve_bwd_generic_kernel<R, false, true, NW, ACCREG>), grid, block, 0, s, a, method, L, bps > 0 ? 1 : 0);
+        else hipLaunchKernelGGL((solve_bwd_generic_kernel<R, false, false, NW, ACCREG>), grid, block, 0, s, a, method, L, bps > 0 ? 1 : 0);
+    }
+    if constexpr (sizeof(R) == 4) {
+        if (bps > 0)
+            launch_adj_reduce(s, reinterpret_cast<const float *>(a.partials), (int)adj_partial_rowlen(a.P), bps, a.n_sets, a.P,
+                              reinterpret_cast<float *>(a.gnn), reinterpret_cast<float *>(a.gode));
     }
     return hipGetLastError() == hipSuccess ? HODE_OK : HODE_ELAUNCH;
 }

@@ -156,7 +156,9 @@ inline size_t tape_partials_offset(int B, int max_steps, size_t elem, int H, int
 inline size_t tape_total_bytes(int B, int max_steps, size_t elem, int H, int L)
 {
     const size_t o = tape_partials_offset(B, max_steps, elem, H, L);
-    if (!tuned_shape(H, L)) return o;            // the generic path flushes coalesced atomics (hode_generic.hip)
+    // (generic shapes: the fp32 team kernels write gradient rows as well since round 4; fp64 and networks with more than four hidden
+    //  matrices keep the coalesced atomics of hode_generic.hip)
+    if (!tuned_shape(H, L) && elem != 4) return o;
     const int P = 9 * H + H + (layers_of(L) - 1) * (H * H + H) + 6 * H + 6;
     return o + (size_t)adj_partial_rows(B) * adj_partial_rowlen(P) * elem;
 }

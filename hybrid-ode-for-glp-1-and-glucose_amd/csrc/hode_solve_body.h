@@ -43,7 +43,11 @@ template <typename R, int NL, typename WT> struct RhsRegs {
             // store to the 8 reals -- identical bits per address -- instead of masking 56 lanes off (exec save / branch / restore)
             int l7 = lane & 7;
             asm volatile("" : "+v"(l7));                    // (recomputed per stage: a hoisted copy costs a VGPR the kernel does not have)
+#ifdef HODE_TAPE_NT
+            __builtin_nontemporal_store(Ys, rec + NL * kWave + l7);
+#else
             rec[NL * kWave + l7] = Ys;
+#endif
             return F;
         }
         return rhs_eval<R, NL, false>(W, o, ts, Ys, meal, tvns, gde, lane, (MlpActs<R, NL> *)nullptr);
