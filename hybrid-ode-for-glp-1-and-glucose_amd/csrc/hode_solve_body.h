@@ -71,6 +71,42 @@ template <typename R> __device__ __forceinline__ float rms6(float sum)
     else return sqrtf(sum / 6.0f);
 }
 
+// Dormand-Prince 5(4) as compile-time constants (the values of kTableau[HODE_METHOD_DP54], hode_device.h): the fp32 solve unrolls its
+// six stages with one register per stage derivative, so a stage combination is a chain of FMAs with literal coefficients
+namespace dp54c {
+constexpr double A[7][6] = {{0, 0, 0, 0, 0, 0},
+                            {1.0 / 5, 0, 0, 0, 0, 0},
+                            {3.0 / 40, 9.0 / 40, 0, 0, 0, 0},
+                            {44.0 / 45, -56.0 / 15, 32.0 / 9, 0, 0, 0},
+                            {19372.0 / 6561, -25360.0 / 2187, 64448.0 / 6561, -212.0 / 729, 0, 0},
+                            {9017.0 / 3168, -355.0 / 33, 46732.0 / 5247, 49.0 / 176, -5103.0 / 18656, 0},
+                            {35.0 / 384, 0, 500.0 / 1113, 125.0 / 192, -2187.0 / 6784, 11.0 / 84}};
+constexpr double C[7] = {0, 1.0 / 5, 3.0 / 10, 4.0 / 5, 8.0 / 9, 1, 1};
+constexpr double E[7] = {-71.0 / 57600, 0, 71.0 / 16695, -71.0 / 1920, 17253.0 / 339200, -22.0 / 525, 1.0 / 40};
+// sum_j A[S][j] K[j] (row 6 = the fifth-order weights), ascending j, zero coefficients skipped, one FMA per term
+template <int S, int J = 1> __device__ __forceinline__ float row_sum(const float (&K)[7], float acc)
+{
+    if constexpr (J < (S < 6 ? S : 6)) {
+        constexpr float a = (float)A[S][J];
+        if constexpr (a != 0.f) acc = __builtin_fmaf(a, K[J], acc);
+        return row_sum<S, J + 1>(K, acc);
+    } else {
+        return acc;
+    }
+}
+template <int S> __device__ __forceinline__ float stage_sum(const float (&K)[7]) { return row_sum<S>(K, (float)A[S][0] * K[0]); }
+template <int J = 1> __device__ __forceinline__ float err_sum(const float (&K)[7], float acc)
+{
+    if constexpr (J < 7) {
+        constexpr float e = (float)E[J];
+        if constexpr (e != 0.f) acc = __builtin_fmaf(e, K[J], acc);
+        return err_sum<J + 1>(K, acc);
+    } else {
+        return acc;
+    }
+}
+}  // namespace dp54c
+
 // rows  [8][64] tableau coefficient rows, cvec [8] tableau nodes (LDS, shared by the workgroup)
 // ybuf  [64 + 8] output staging of THIS wave (LDS)
 // rhs   the right-hand side functor of trajectory b's parameter set; o = its 17 mechanistic constants (Hill term)
@@ -128,6 +164,11 @@ __device__ __forceinline__ void solve_one(const SolveArgs<R> &a, const int b, co
     int st = HODE_ST_OK, ns = 0, nf = 0, k = 0;
     R h_abs = R(0);
     R KK = R(0);                              // packed stage derivatives: lanes 8s..8s+7 = K_{s+1}
+    // fp32 DP5(4): the stages are unrolled and every stage derivative has a register of its own (replicated layout, like Y):
+    // a stage combination is <= 6 FMAs with literal coefficients -- no packed register, no coefficient row from LDS, no 7-instruction
+    // cross-lane sum, no slot select (12 vector instructions per stage in the rolled form, ~4.5 here).  KF = the FSAL derivative.
+    constexpr bool kUnrolled = METHOD == HODE_METHOD_DP54 && sizeof(R) == 4 && !GD;       // (the Hill term's two pow calls x 6 stages: scratch)
+    R KF = R(0);
     bool have_f = false;
 
     for (; k + 1 < T && st == HODE_ST_OK; ++k) {
@@ -205,7 +246,8 @@ __device__ __forceinline__ void solve_one(const SolveArgs<R> &a, const int b, co
                 const float h1 = (dn1 <= 1e-15f && dn2 <= 1e-15f) ? fmaxf(1e-6f, h0 * 1e-3f)
                                                                    : powf(0.01f / fmaxf(dn1, dn2), 0.2f);
                 h_abs = first_lane((R)fminf(fminf(100.0f * h0, h1), (float)len));
-                KK = (grp == 0) ? K1 : R(0);
+                if constexpr (kUnrolled) KF = K1;
+                else KK = (grp == 0) ? K1 : R(0);
                 nf += 2;
                 have_f = true;
             }
@@ -220,15 +262,27 @@ __device__ __forceinline__ void solve_one(const SolveArgs<R> &a, const int b, co
                     if (tn >= t1 || (t1 - tn) < R(0.01) * h) { tn = t1; h = tn - tc; clipped = true; }
                     h = first_lane(h);
                     tn = first_lane(tn);
+                    const bool fsal_fits = ns + 1 < a.max_steps;
+                    R Ys = Y, F = R(0), err;
+                    if constexpr (kUnrolled) {
+                        float K[7];
+                        K[0] = KF;
+#define HODE_DP_STAGE(S)                                                                                                        \
+                        Ys = rfma(h, dp54c::stage_sum<S>(K), Y);                                                               \
+                        K[S] = f_at((S) >= 5 ? tn : first_lane(rfma((float)dp54c::C[S], h, tc)), Ys,                            \
+                                    ((S) < 6 || fsal_fits) ? rec_at(ns * 6 + (S)) : nullptr);
+                        HODE_DP_STAGE(1) HODE_DP_STAGE(2) HODE_DP_STAGE(3) HODE_DP_STAGE(4) HODE_DP_STAGE(5) HODE_DP_STAGE(6)
+#undef HODE_DP_STAGE
+                        F = K[6];
+                        err = h * dp54c::err_sum(K, (float)dp54c::E[0] * K[0]);
+                    } else {
                     KK = (grp == 0) ? KK : R(0);          // drop stale stages (0 * NaN would poison the sums)
-                    R Ys = Y, F = R(0);
                     // the coefficient row and node of stage s+1 are fetched from LDS BEFORE the RHS of stage s,
                     // so the LDS latency hides behind the MLP instead of opening every stage
                     R coef = rows[1 * kWave + lane], cs = cvec[1];
                     // stage s writes record 6 ns + s (s = 6, the FSAL stage, is record 0 of the NEXT step).  ns < max_steps holds
                     // here, so only the FSAL stage can fall off the tape: one flag per step instead of a range check of the slot
                     // at every stage (twelve scalar instructions, every one an issue slot of the wave)
-                    const bool fsal_fits = ns + 1 < a.max_steps;
 #pragma unroll 1
                     for (int s = 1; s <= 6; ++s) {        // stages 2..6 and the FSAL stage (row 6 = 5th-order weights)
                         Ys = rfma(h, group_sum8(coef * KK), Y);
@@ -241,9 +295,10 @@ __device__ __forceinline__ void solve_one(const SolveArgs<R> &a, const int b, co
                         F = f_at(ts, Ys, (s < 6 || fsal_fits) ? rec_at(ns * 6 + s) : nullptr);
                         KK = stage_put(KK, F, s);
                     }
+                    err = h * group_sum8(coef * KK);
+                    }
                     const R Yn = Ys;                      // 5th-order solution
                     nf += 6;
-                    const R err = h * group_sum8(coef * KK);
                     const R ymax = rabs(Y) > rabs(Yn) ? rabs(Y) : rabs(Yn);
                     const R qe = (c8 < 6) ? rdiv(err, a.atol + ymax * a.rtol) : R(0);
                     float en = first_lane(rms6<R>((float)first_lane(oct_allsum(qe * qe))));   // scalar from here on
@@ -256,7 +311,8 @@ __device__ __forceinline__ void solve_one(const SolveArgs<R> &a, const int b, co
                         const R hn = first_lane(h * (R)fac);
                         h_abs = (clipped && hn < h_abs) ? h_abs : hn;               // a clipped step never shrinks the proposal
                         Y = Yn;
-                        KK = (grp == 0) ? F : KK;         // FSAL: K7 becomes K1
+                        if constexpr (kUnrolled) KF = F;
+                        else KK = (grp == 0) ? F : KK;    // FSAL: K7 becomes K1
                         tc = tn;
                         ns++;
                         break;
