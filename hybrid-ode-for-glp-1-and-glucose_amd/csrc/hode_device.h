@@ -513,6 +513,7 @@ __device__ __forceinline__ float mlp_hidden_relu(const float (&w)[kMaxH], float 
 // (q0 + q1) + (q2 + q3) + b: the order every fp32 kernel of this library uses.  Every swap reads data at least two instructions old.
 template <bool RELU, bool BIAS> __device__ __forceinline__ float blk_rows_finish(f2_t a02, f2_t a13, float bias)
 {
+#ifndef HODE_FINISH_SPLIT
     asm("s_nop 1\n\t"                          /* (hipcc may have just COPIED an accumulator) */
         "v_permlane16_swap_b32 %[a2], %[a3]\n\t" /* a2 = [u2.q0 u3.q0 u2.q2 u3.q2]   a3 = [u2.q1 u3.q1 u2.q3 u3.q3] */
         "s_nop 0\n\t"
@@ -520,6 +521,18 @@ template <bool RELU, bool BIAS> __device__ __forceinline__ float blk_rows_finish
         : [a0] "+v"(a02.x), [a2] "+v"(a02.y), [a1] "+v"(a13.x), [a3] "+v"(a13.y));
     asm("s_nop 0\n\tv_pk_add_f32 %0, %0, %1" : "+v"(a02) : "v"(a13));     // rows: u0 / u2 q0+q1, u1 / u3 q0+q1, q2+q3, q2+q3
     float a0 = a02.x, a2 = a02.y;
+#else
+    // On the four accumulators as FOUR 32-bit operands of one statement (the halves are free to read; as read-write halves of the two
+    // pairs, hipcc wrapped the swaps of two layers out of three in a copy out of and back into a pair): two swaps, two adds
+    float a0 = a02.x, a2 = a02.y, a1 = a13.x, a3 = a13.y;
+    asm("s_nop 1\n\t"
+        "v_permlane16_swap_b32 %[a2], %[a3]\n\t" /* a2 = [u2.q0 u3.q0 u2.q2 u3.q2]   a3 = [u2.q1 u3.q1 u2.q3 u3.q3] */
+        "s_nop 0\n\t"
+        "v_permlane16_swap_b32 %[a0], %[a1]\n\t" /* a0 = [u0.q0 u1.q0 u0.q2 u1.q2]   a1 = [u0.q1 u1.q1 u0.q3 u1.q3] */
+        "v_add_f32 %[a2], %[a2], %[a3]\n\t"      /* rows: u2 / u3 q0+q1, q2+q3 */
+        "v_add_f32 %[a0], %[a0], %[a1]"           /* rows: u0 / u1 q0+q1, q2+q3  (the same sums as the packed add: (q0 + q1), (q2 + q3)) */
+        : [a0] "+v"(a0), [a2] "+v"(a2), [a1] "+v"(a1), [a3] "+v"(a3));
+#endif
     if constexpr (BIAS) {
         if constexpr (RELU) {
             asm("s_nop 1\n\tv_permlane32_swap_b32 %[a0], %[a2]\n\tv_add_f32 %[a0], %[a0], %[a2]\n\tv_add_f32 %[a0], %[a0], %[bias]\n\tv_max_f32 %[a0], 0, %[a0]"
@@ -557,6 +570,49 @@ template <bool RELU> __device__ __forceinline__ float mlp_hidden_blk(const f2_t 
 {
     // accumulator pairs (a0, a2) and (a1, a3): after the two 16-lane swaps the sums a0 + a1 and a2 + a3 are ONE packed add
     f2_t a02, a13, hr;
+#ifndef HODE_BLK_UNPINNED
+    // The accumulators live in v[4:7] BY NAME (constraint {v[..]} on every statement of the layer, so that the register
+    // allocator keeps them there from the first product to the last swap): the finish can then swap HALVES of the pairs and add
+    // the PAIRS -- 2 swaps + 1 packed add.  With allocator-chosen pairs the halves are separate operands, and hipcc wrapped the
+    // swaps of two layers out of three in a copy out of a pair and back (5 instructions; tools/fwd_valu.py).  Kernels that hold
+    // the weights in registers run at two waves per SIMD (256 registers), so v4..255 exist wherever this function is used.
+#define HODE_A02 "+{v[4:5]}"(a02)
+#define HODE_A13 "+{v[6:7]}"(a13)
+    {
+        f2_t hh;
+        hh.x = h;
+        asm("v_pk_mul_f32 v[4:5], %2, %4 op_sel_hi:[1,0]\n\tv_pk_mul_f32 v[6:7], %3, %4 op_sel_hi:[1,0]"
+            : "=&{v[4:5]}"(a02), "=&{v[6:7]}"(a13) : "v"(wp[0]), "v"(wp[1]), "v"(hh));
+    }
+#define HODE_BK_STEP(n)                                                                                                        \
+    {                                                                                                                          \
+        float lo;                                                                                                              \
+        asm("v_mov_b32_dpp %0, %1 row_ror:" #n " row_mask:0xf bank_mask:0xf" : "=v"(lo) : "v"(h));                             \
+        hr.x = lo;                                                                                                             \
+        asm("v_pk_fma_f32 v[4:5], %2, %4, v[4:5] op_sel_hi:[1,0,1]\n\tv_pk_fma_f32 v[6:7], %3, %4, v[6:7] op_sel_hi:[1,0,1]" \
+            : HODE_A02, HODE_A13 : "v"(wp[2 * n]), "v"(wp[2 * n + 1]), "v"(hr));                                               \
+    }
+    HODE_BK_STEP(1) HODE_BK_STEP(2) HODE_BK_STEP(3) HODE_BK_STEP(4) HODE_BK_STEP(5) HODE_BK_STEP(6) HODE_BK_STEP(7) HODE_BK_STEP(8)
+    HODE_BK_STEP(9) HODE_BK_STEP(10) HODE_BK_STEP(11) HODE_BK_STEP(12) HODE_BK_STEP(13) HODE_BK_STEP(14) HODE_BK_STEP(15)
+#undef HODE_BK_STEP
+    // a02 = v4 (a0), v5 (a2); a13 = v6 (a1), v7 (a3).  Same sums as blk_rows_finish: (q0 + q1) + (q2 + q3) + b
+    asm("s_nop 1\n\t"
+        "v_permlane16_swap_b32 v5, v7\n\t"   /* a2 = [u2.q0 u3.q0 u2.q2 u3.q2]   a3 = [u2.q1 u3.q1 u2.q3 u3.q3] */
+        "s_nop 0\n\t"
+        "v_permlane16_swap_b32 v4, v6\n\t"   /* a0 = [u0.q0 u1.q0 u0.q2 u1.q2]   a1 = [u0.q1 u1.q1 u0.q3 u1.q3] */
+        "s_nop 0\n\t"
+        "v_pk_add_f32 v[4:5], v[4:5], v[6:7]\n\t"     /* rows: u0 / u2 q0+q1, u1 / u3 q0+q1, q2+q3, q2+q3 */
+        "s_nop 1\n\t"
+        "v_permlane32_swap_b32 v4, v5\n\t"
+        "v_add_f32 v4, v4, v5\n\t"
+        "v_add_f32 v4, v4, %[bias]"
+        : HODE_A02, HODE_A13 : [bias] "v"(bias));
+#undef HODE_A02
+#undef HODE_A13
+    float r = a02.x;
+    if constexpr (RELU) asm("v_max_f32 %0, 0, %0" : "+v"(r));
+    return r;
+#else
     // n = 0: the lane's own activation (no rotation); plain products start the sums (h is a fresh VALU result: these two
     // instructions are also the wait states its first DPP read needs)
     {
@@ -576,6 +632,7 @@ template <bool RELU> __device__ __forceinline__ float mlp_hidden_blk(const f2_t 
     HODE_BK_STEP(9) HODE_BK_STEP(10) HODE_BK_STEP(11) HODE_BK_STEP(12) HODE_BK_STEP(13) HODE_BK_STEP(14) HODE_BK_STEP(15)
 #undef HODE_BK_STEP
     return blk_rows_finish<RELU, true>(a02, a13, bias);
+#endif
 }
 // acc[q] += sum_n row_ror:n(R[q]) * w[16 q + n], n ascending within each accumulator; R[] must be two wait states old
 __device__ __forceinline__ void rot_matvec64(const float (&w)[kMaxH], const float (&R)[4], float (&acc)[4])
@@ -794,9 +851,16 @@ __device__ __forceinline__ float out_rot(const float (&w)[8], float b5m, float h
         HODE_OR(1) HODE_OR(2) HODE_OR(3) HODE_OR(4) HODE_OR(5) HODE_OR(6) HODE_OR(7)
         "s_nop 1\n\t"
         "v_add_f32_dpp %[a], %[a], %[a] row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+#ifndef HODE_OUT_ROT_SWIZZLE
         "v_mov_b32 %[t], %[a]\n\t"
         "s_nop 1\n\t"
         "v_permlane16_swap_b32 %[a], %[t]\n\t"       // a = [r0 r0 r2 r2], t = [r1 r1 r3 r3]
+#else
+        // experiment: the partner row (lane ^ 16) through the LDS crossbar -- ds_swizzle_b32, BITMASK_PERM xor 0x10 -- saves
+        // two vector instructions per right-hand side and measured 1.5 % SLOWER: its latency sits on the stage's dependent chain
+        "ds_swizzle_b32 %[t], %[a] offset:0x401f\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+#endif
         "v_add_f32 %[a], %[a], %[t]\n\t"             // [r0+r1 x2, r2+r3 x2]
         "v_mov_b32 %[t], %[a]\n\t"
         "s_nop 1\n\t"

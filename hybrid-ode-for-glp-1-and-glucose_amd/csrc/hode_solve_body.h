@@ -18,6 +18,17 @@ template <typename R> __device__ __forceinline__ R inp_at(const R *__restrict__ 
     return (mode == 1) ? p[b] : p[(size_t)b * T + k];
 }
 
+// The same value through the SCALAR data cache: b and k are wave-uniform (one trajectory per wave) and the time grid and the forcing rows
+// are read-only for the whole launch, so the load may take the constant address space -- s_load_dword, counted by lgkmcnt like an LDS
+// read, not by vmcnt where it would queue behind the taping kernel's stores.  solve_one issues it ONE GRID INTERVAL AHEAD.
+template <typename R> __device__ __forceinline__ R inp_at_uniform(const R *p, int mode, int b, int T, int k)
+{
+    typedef const __attribute__((address_space(4))) R CR;
+    if (mode == 0) return R(0);
+    const size_t i = (mode == 1) ? (size_t)b : (size_t)b * T + k;
+    return *((CR *)(uintptr_t)p + i);
+}
+
 template <typename R> struct Eps;
 template <> struct Eps<float> { static constexpr float v = 1.1920929e-7f; };
 template <> struct Eps<double> { static constexpr double v = 2.220446049250313e-16; };
@@ -117,7 +128,6 @@ __device__ __forceinline__ void solve_one(const SolveArgs<R> &a, const int b, co
 {
     const int c8 = lane & 7, grp = lane >> 3;
     const int T = a.T;
-    const R *__restrict__ tg = a.t + (a.t_batched ? (size_t)b * T : 0);
     R *__restrict__ yb = a.y + (size_t)b * T * 6;
     R *__restrict__ tape = TAPE ? a.tape + (size_t)b * a.max_steps * 8 : nullptr;
     int *__restrict__ tseg = TAPE ? a.tape_seg + (size_t)b * a.max_steps : nullptr;
@@ -171,13 +181,25 @@ __device__ __forceinline__ void solve_one(const SolveArgs<R> &a, const int b, co
     R KF = R(0);
     bool have_f = false;
 
-    for (; k + 1 < T && st == HODE_ST_OK; ++k) {
-        const R t0 = tg[k], t1 = tg[k + 1];
-        const R m0 = inp_at(a.meal, a.meal_mode, b, T, k), m1 = inp_at(a.meal, a.meal_mode, b, T, k + 1);
-        const R v0 = inp_at(a.tvns, a.tvns_mode, b, T, k), v1 = inp_at(a.tvns, a.tvns_mode, b, T, k + 1);
-        const R d0 = inp_at(a.gd, a.gd_mode, b, T, k), d1 = inp_at(a.gd, a.gd_mode, b, T, k + 1);
+    // Grid point k + 2 is fetched at the top of interval k and first touched when interval k + 1 begins (every trajectory of the
+    // benchmark takes ONE step per interval: fetched where they are used, the six loads of an interval and their full wait -- an L2
+    // round trip, with the taping kernel's stores in the same queue -- opened every step of the integration; profiles/r04_pmc_fwd.log)
+    const int tb = a.t_batched ? b : 0;
+    auto grid_at = [&](int kk, R &tq, R &mq, R &vq, R &dq) {
+        kk = kk < T ? kk : T - 1;
+        tq = inp_at_uniform(a.t, 2, tb, T, kk);
+        mq = inp_at_uniform(a.meal, a.meal_mode, b, T, kk);
+        vq = inp_at_uniform(a.tvns, a.tvns_mode, b, T, kk);
+        dq = GD ? inp_at_uniform(a.gd, a.gd_mode, b, T, kk) : R(0);
+    };
+    R t0, m0, v0, d0, t1, m1, v1, d1, t2, m2, v2, d2;
+    grid_at(0, t0, m0, v0, d0);
+    grid_at(1, t1, m1, v1, d1);
+    t2 = t1, m2 = m1, v2 = v1, d2 = d1;
+    for (; k + 1 < T && st == HODE_ST_OK; ++k, t0 = t1, m0 = m1, v0 = v1, d0 = d1, t1 = t2, m1 = m2, v1 = v2, d1 = d2) {
         const R len = t1 - t0;
         if (!(len > R(0))) {                  // repeated grid time: copy the state
+            grid_at(k + 2, t2, m2, v2, d2);
             y_put(Y);
             continue;
         }
@@ -211,6 +233,7 @@ __device__ __forceinline__ void solve_one(const SolveArgs<R> &a, const int b, co
             }
         };
         R tc = t0;
+        grid_at(k + 2, t2, m2, v2, d2);       // (behind the interval's own constants: hipcc waits for every scalar load before the division)
 
         if constexpr (METHOD == HODE_METHOD_RK4) {
             if (ns >= a.max_steps) { st = HODE_ST_MAXSTEPS; break; }     // budget < T-1: report, never overrun the tape
