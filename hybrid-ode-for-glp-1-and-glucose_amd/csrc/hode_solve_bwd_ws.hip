@@ -9,21 +9,32 @@
 // fill in.  The accumulators are sums over ALL stages of ALL trajectories -- they do not have to live where the cotangent is
 // propagated.  A workgroup of 16 waves (one per CU, 4 per SIMD, <= 128 VGPRs) splits the work by ROLE:
 //
-//   P  8 propagation waves   U (1 or 2) trajectories each, interleaved instruction by instruction: a lone wave issues a
-//                            dependent instruction every ~9 cycles, two independent chains fill each other's gaps, and the two
-//                            share every 16-byte read of the transposed matrices.  Per stage and trajectory: record (h_1..h_NL,
-//                            stage state) by LDS-DMA, kb, mechanistic J^T, delta_NL .. delta_1 through the transposed matrices
-//                            (LDS image, rotating-operand order).  No gradient accumulators.  Publishes delta_1..delta_NL, kb,
-//                            t, tVNS in an LDS hand-off slot (1.25 KB per trajectory, double buffered).
-//   A  8 accumulation waves  A_j owns dW of hidden matrix j % (NL-1) -- 64 accumulators -- for its share of the 8 U trajectory
-//                            slots: dW_m += delta_{m+1} (x) h_m, 64 v_fmac_f32_dpp per slot and stage, operands straight
-//                            from LDS (the slot's record and hand-off), + the bias of that layer; A_4..A_7 also keep the
-//                            first / last layer gradients (17 accumulators) of a quarter of the slots each.
+//   P  8 propagation waves   U (1 or 2) trajectories each, interleaved instruction by instruction (two independent chains fill each
+//                            other's gaps and share every 16-byte read of the transposed matrices).  Per stage and trajectory: the
+//                            stage record (h_1..h_NL, stage state) by LDS-DMA into a ring of three slots; the STEP HEADER -- the
+//                            32-byte tape entry {t, h, t0, 1/len, v0, dv, d0, dd}, up to six cotangent rows gy and the interval word,
+//                            gathered by ONE LDS-DMA with per-lane global addresses one step ahead (hdr_dma -> hdrs[][2][64]; the
+//                            slow `inject` path only for a failed first step or more than six rows at one step); kb; mechanistic
+//                            J^T; delta_NL .. delta_1 through the transposed matrices (LDS image in row-block order: one
+//                            v_mov_b32_dpp / 16-byte broadcast read of delta + two v_pk_fma_f32 per rotation).  No gradient
+//                            accumulators.  Publishes delta_1..delta_NL, kb, t, tVNS in an LDS hand-off slot (1.25 KB per
+//                            trajectory, double buffered).
+//   A  8 accumulation waves  A_j owns dW of hidden matrix j % (NL-1) -- 64 accumulators in natural column order -- for its share of
+//                            the 8 U trajectory slots: dW_m += delta_{m+1} (x) h_m with the 16 values of h_m's row as four 16-byte
+//                            LDS broadcast reads and 32 v_pk_fma_f32 per slot and stage (ws_outer_nat; round 3: 15 v_mov_b32_dpp
+//                            instead of the reads -- the LDS pipe has room, the vector pipe does not), + the layer's bias; the
+//                            first / last layer gradients (17 accumulators) belong to the waves of ws_edge_owner -- the six that
+//                            serve the fewest matrix slots.
+//
+// LDS reads of regions an LDS-DMA may be writing are inline asm (ws_lds_read128 + ws_lds_wait*): in front of a compiler-visible read
+// of such a region hipcc waits for EVERY outstanding vector-memory operation (s_waitcnt vmcnt(0)) -- the record DMA issued a moment
+// ago included (+1 000 cycles per stage in the mechanistic phase).
 //
 // Everything is in lock step: one s_barrier per stage.  In iteration i the P-waves process stage i of their trajectories while
 // the A-waves consume what was published in iteration i - 1 (hand-off double buffered, record ring of three slots), so nobody
 // polls and every wave reaches every barrier: the iteration count is the maximum over the slots of their total stage count, + 1.
-// With U = 2 a 4 096-trajectory batch is ONE round of 16 trajectories per CU.
+// With U = 2 a 4 096-trajectory batch is ONE round of 16 trajectories per CU.  What a stage waits for is the propagation chain
+// (P-waves alone: 5.1 of the 5.6-5.8 ms).
 //
 // Determinism: every A-wave adds its slots' products in slot order, the waves of a matrix are summed in rank order, the workgroup
 // writes ONE gradient row to a.partials and adj_reduce_kernel adds the rows in workgroup order: no floating-point atomics

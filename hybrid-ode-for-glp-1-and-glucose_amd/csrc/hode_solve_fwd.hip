@@ -9,16 +9,20 @@
 
 namespace hode {
 
-template <typename R, int NL, int METHOD, int LB, bool TAPE, bool GD>
-__global__ __launch_bounds__(64, LB) void solve_fwd_kernel(const SolveArgs<R> a)
+// MULTI: launches of MANY SHORT trajectories of ONE parameter set (the two-point solves of the physics loss: 81 920 per 4 096-patient
+// step, a dozen evaluations each) hand every wave `chunk` consecutive trajectories, so that the 54 KB of weights are gathered from L2
+// once per wave and not once per trajectory (half of such a launch's time).  A separate instantiation: the loop is kept out of the
+// kernels every other launch runs.
+template <typename R, int NL, int METHOD, int LB, bool TAPE, bool GD, bool MULTI>
+__global__ __launch_bounds__(64, LB) void solve_fwd_kernel(const SolveArgs<R> a, const int chunk)
 {
     __shared__ R rows[8 * kWave];             // tableau coefficient rows (hode_device.h)
     __shared__ R cvec[8];                     // tableau nodes c[s] as reals
     __shared__ R ybuf[kWave + 8];             // output staging: rows of 6 reals are gathered into 256-byte stores
     __shared__ R wstage[(sizeof(R) == 4) ? kStageElems : 1];   // weight-row permutation scratch (prologue only)
     const int lane = threadIdx.x;
-    const int b = blockIdx.x;                 // one wave == one trajectory
-    const int set = b / (a.B / a.n_sets);
+    const int b0 = MULTI ? blockIdx.x * chunk : blockIdx.x;                 // one wave == one trajectory (MULTI: one after the other)
+    const int set = b0 / (a.B / a.n_sets);
 
     tableau_rows_store<R>(rows, METHOD, lane, 64);
     if (lane < 8) cvec[lane] = (R)kTableau[METHOD].c[lane];
@@ -28,7 +32,13 @@ __global__ __launch_bounds__(64, LB) void solve_fwd_kernel(const SolveArgs<R> a)
     ode_load(o, a.ode_p + 17 * set);
     __syncthreads();
     const RhsRegs<R, NL, MlpRegs<R, NL>> rhs{W, o, lane};
-    solve_one<R, METHOD, TAPE, GD>(a, b, rhs, o, rows, cvec, ybuf, lane);
+    if constexpr (MULTI) {
+        const int b1 = (b0 + chunk < a.B) ? b0 + chunk : a.B;
+#pragma unroll 1
+        for (int b = b0; b < b1; ++b) solve_one<R, METHOD, TAPE, GD>(a, b, rhs, o, rows, cvec, ybuf, lane);
+    } else {
+        solve_one<R, METHOD, TAPE, GD>(a, b0, rhs, o, rows, cvec, ybuf, lane);
+    }
 }
 
 template <typename R, int NL, int METHOD, bool TAPE, bool GD>
@@ -36,7 +46,15 @@ static void launch_one(hipStream_t s, const SolveArgs<R> &a)
 {
     // waves per SIMD the register budget allows: 211 weight registers for 3 hidden matrices -> 2; fewer layers -> more
     constexpr int LB = (sizeof(R) == 4) ? (NL >= 3 ? 2 : (NL == 2 ? 3 : 4)) : 1;
-    hipLaunchKernelGGL((solve_fwd_kernel<R, NL, METHOD, LB, TAPE, GD>), dim3(a.B), dim3(64), 0, s, a);
+    if constexpr (!TAPE && !GD && METHOD == HODE_METHOD_DP54 && sizeof(R) == 4) {
+        // grid points <= 4, one parameter set, more trajectories than four rounds of the chip's 2 048 wave slots: see the kernel
+        if (a.T <= 4 && a.n_sets == 1 && a.B > 8192) {
+            const int chunk = (a.B + 8191) / 8192;
+            hipLaunchKernelGGL((solve_fwd_kernel<R, NL, METHOD, LB, TAPE, GD, true>), dim3((a.B + chunk - 1) / chunk), dim3(64), 0, s, a, chunk);
+            return;
+        }
+    }
+    hipLaunchKernelGGL((solve_fwd_kernel<R, NL, METHOD, LB, TAPE, GD, false>), dim3(a.B), dim3(64), 0, s, a, 1);
 }
 
 template <typename R, int NL>

@@ -543,3 +543,26 @@ def test_ws_adjoint_two_trajectories_per_wave_with_parameter_sets(hode):
         assert max(relnorm(gx.cpu().numpy()[i], gxo[j]) for j, i in enumerate(idx)) < 1e-4
     # the two sets' gradients differ (the launch did not hand one set's rows to the other)
     assert relnorm(gnn[:P].cpu().numpy(), gnn[P:].cpu().numpy()) > 1e-2
+
+
+def test_many_short_trajectories_per_wave_equal_one_trajectory_per_wave(hode):
+    """The physics term of loss() at 4 096 patients is 81 920 two-point solves (reference models/hybrid_ode_nn.py:318-330): above
+    8 192 trajectories of <= 4 grid points and one parameter set a wave integrates several, one after the other, with the weights
+    loaded once.  Same bits as the launches of <= 8 192 that take the one-trajectory kernel; a sample against the fp64 oracle."""
+    B = 20011                                                       # 3 per wave, the last wave short
+    x0, _, meal, tvns = bench.synth_cohort(B, 77)
+    g = torch.Generator().manual_seed(9)
+    x0 = (x0 * (0.5 + torch.rand(B, 6, generator=g))).cuda()
+    m, v = (meal[:, 40] * torch.rand(B, generator=g)).cuda().contiguous(), torch.rand(B, generator=g).cuda()
+    t = torch.tensor([0.0, 0.1], device="cuda")
+    nn, ode = bench.synth_weights(0).cuda(), bench.ODE_DEFAULT.cuda()
+    big = hode.solve_fwd(x0, t, m, v, None, ode, nn, H, L)
+    parts = [hode.solve_fwd(x0[lo:lo + 8192].contiguous(), t, m[lo:lo + 8192].contiguous(), v[lo:lo + 8192].contiguous(), None, ode, nn, H, L)
+             for lo in range(0, B, 8192)]
+    assert torch.equal(big.y, torch.cat([p.y for p in parts])) and int(big.status.max()) == 0
+    assert torch.equal(big.nsteps, torch.cat([p.nsteps for p in parts])) and torch.equal(big.nfev, torch.cat([p.nfev for p in parts]))
+    idx = [0, 1, 2, 8191, 8192, 12345, B - 2, B - 1]
+    ref = O.solve(x0[idx].cpu().numpy().astype(np.float64), np.array([0.0, 0.1]), m[idx].cpu().numpy().astype(np.float64),
+                  v[idx].cpu().numpy().astype(np.float64), None, ode.cpu().numpy().astype(np.float64), nn.cpu().numpy().astype(np.float64),
+                  H, L, rtol=1e-10, atol=1e-12, dtype=np.float64)
+    assert relnorm(big.y[idx].cpu().numpy(), ref.y) < 1e-5

@@ -14,7 +14,7 @@ subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx9
                 "-Wno-unused-function", *sys.argv[1:], SRC, "-o", out], check=True)
 txt = open(out).read()
 for tape in ("0", "1"):
-    name = f"_ZN4hode16solve_fwd_kernelIfLi4ELi0ELi2ELb{tape}ELb0EEEvNS_9SolveArgsIT_EE"
+    name = f"_ZN4hode16solve_fwd_kernelIfLi4ELi0ELi2ELb{tape}ELb0ELb0EEEvNS_9SolveArgsIT_EEi"
     m = re.search(rf"^{re.escape(name)}:[^\n]*\n(.*?)\n\s*s_endpgm", txt, re.S | re.M)
     if not m:
         print("kernel not found:", name); continue

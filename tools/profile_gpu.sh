@@ -18,9 +18,9 @@ cd /tmp
 ARGS="--steps 5 --warmup 2 --train-steps 2 --no-cpu-baseline --no-vi --no-generic --no-zscore --no-sobol --no-class-path --no-build"
 # the kernel sources these counters belong to (bench.py reports PMC traffic only while this hash matches)
 python3 -c "import sys; sys.path.insert(0, '$R'); import bench; print(bench.kernel_source_sha())" > $OUT/kernel_source_sha.txt
-# the trace pass runs the bench's own 20 steps + 5 warm-up launches: the first launches of a process are slower (clocks, cold
-# caches; 3.8 against 3.47 ms), with 8 launches they moved the average 4 % above ms_per_step
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --steps 20 --warmup 5 --train-steps 5 --no-cpu-baseline --no-vi --no-generic --no-zscore --no-sobol --no-class-path --no-build > $OUT/bench_trace.log 2>&1
+# the trace pass runs 40 + 5 forward launches and 20 training steps: the first launches of a process are slower (clocks, cold
+# caches), with 11 adjoint launches they moved its average 5 % above the bench's figure
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --steps 40 --warmup 5 --train-steps 20 --no-cpu-baseline --no-vi --no-generic --no-zscore --no-sobol --no-class-path --no-build > $OUT/bench_trace.log 2>&1
 echo "trace done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_zscore -- python3 $R/tools/zscore_launches.py > $OUT/bench_trace_zscore.log 2>&1
 echo "zscore trace done"

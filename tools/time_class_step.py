@@ -16,7 +16,7 @@ from models import HybridODENN  # noqa: E402
 
 dev = torch.device("cuda")
 for B in [int(v) for v in sys.argv[1:]] or [32, 256]:
-    T = 61
+    T = int(os.environ.get("HODE_T", "61"))
     x0, t, meal, tvns = (v.to(dev) for v in bench.synth_cohort(B, 1000))
     t, meal, tvns = t[:T].contiguous(), meal[:, :T].contiguous(), tvns[:, :T].contiguous()
     torch.manual_seed(0)
