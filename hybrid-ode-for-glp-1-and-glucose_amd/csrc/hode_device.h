@@ -879,14 +879,29 @@ __device__ __forceinline__ float out_rot(const float (&w)[8], float b5m, float h
 //       fp32 reads lane k of EVERY 16-lane row for x_k, fp64 lane k of the wave)
 //   returns the derivative in the same replicated layout (component slots 6,7 hold 0)
 //   W   weights holder: MlpRegs (everything in VGPRs) or MlpLds (hidden matrices in a workgroup-shared LDS image)
+#ifdef HODE_FWD_TRACE
+// experiment build only (tools/build_variant.sh fwdtrace -DHODE_FWD_TRACE=<workgroup>; tools/fwd_trace.py): shader-clock stamps of ONE
+// wave at six points of every right-hand side it evaluates -- entry | mechanistic terms | first layer | hidden layers 1..3 | return --, in a ring of 4 096 records
+static __device__ unsigned long long g_ft[4096 * 8];
+static __device__ unsigned g_ft_n;
+#define HODE_FT(i, v) if (ft_on) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ft[i]), "+v"(v))
+#else
+#define HODE_FT(i, v)
+#endif
 template <typename R, int NL, bool KEEP, typename WT, typename ACTS = MlpActs<R, NL>>
 __device__ __forceinline__ R rhs_eval(const WT &W, const OdeP<R> &o, R t, R Y, R meal, R tvns,
                                       R gde /* Hill term, 0 without GD */, int lane, ACTS *acts)
 {
+#ifdef HODE_FWD_TRACE
+    const bool ft_on = sizeof(R) == 4 && NL == 4 && blockIdx.x == HODE_FWD_TRACE;
+    unsigned long long ft[8] = {};
+#endif
+    HODE_FT(0, Y);
     const R G = state_bcast<0>(Y), I = state_bcast<1>(Y), Glu = state_bcast<2>(Y), GLP1 = state_bcast<3>(Y),
             FFA = state_bcast<5>(Y);
     const int c8 = lane & 7;
-    const R mech = mech_eval(o, G, I, Glu, GLP1, FFA, meal, gde, c8);
+    R mech = mech_eval(o, G, I, Glu, GLP1, FFA, meal, gde, c8);
+    HODE_FT(6, mech);
     // ---- MLP (models/nn_residual.py:138-147): input row [t, G, I, Glu, GLP1, GE, FFA, glp1:=GLP1, tvns]
     R h = W.b[0];
     h = rfma(W.w1[0], t, h);
@@ -898,17 +913,29 @@ __device__ __forceinline__ R rhs_eval(const WT &W, const OdeP<R> &o, R t, R Y, R
     h = rfma(W.w1[6], FFA, h);
     h = rfma(W.w1[8], tvns, h);
     h = rmax0(h);
+    HODE_FT(1, h);
     if constexpr (KEEP) acts->put(0, h);
 #pragma unroll
     for (int l = 0; l < NL - 1; ++l) {
         if constexpr (applies_relu<WT>::value) h = W.hidden_relu(l, h);
         else h = rmax0(W.hidden(l, h));
+        HODE_FT(2 + l, h);
         if constexpr (KEEP) acts->put(l + 1, h);
     }
     if constexpr (sizeof(R) == 4) {
         // out_rot leaves Wout h + bout on the lanes of slot c8 < 6 and exact zeros on slots 6, 7 (zero weights, zero bias);
         // the mechanistic select chain ends in zero there as well: no final select
-        return mech + out_rot(W.w5r, W.b5, h);
+        R res = mech + out_rot(W.w5r, W.b5, h);
+        HODE_FT(5, res);
+#ifdef HODE_FWD_TRACE
+        if (ft_on && lane == 0) {
+            // slot = a hash of the entry time (an evaluation takes > 2 000 cycles: consecutive ones fall into different slots); a counter
+            // in memory would put a load round trip between every two evaluations of the wave that is being measured
+            const unsigned n = (unsigned)(ft[0] >> 10);
+            for (int i = 0; i < 8; ++i) g_ft[(n & 4095) * 8 + i] = ft[i];
+        }
+#endif
+        return res;
     }
     R nn;
     {

@@ -21,13 +21,22 @@ template <typename R> __device__ __forceinline__ R inp_at(const R *__restrict__ 
 // The same value through the SCALAR data cache: b and k are wave-uniform (one trajectory per wave) and the time grid and the forcing rows
 // are read-only for the whole launch, so the load may take the constant address space -- s_load_dword, counted by lgkmcnt like an LDS
 // read, not by vmcnt where it would queue behind the taping kernel's stores.  solve_one issues it ONE GRID INTERVAL AHEAD.
-template <typename R> __device__ __forceinline__ R inp_at_uniform(const R *p, int mode, int b, int T, int k)
-{
+template <typename R> struct UniformInput {
     typedef const __attribute__((address_space(4))) R CR;
-    if (mode == 0) return R(0);
-    const size_t i = (mode == 1) ? (size_t)b : (size_t)b * T + k;
-    return *((CR *)(uintptr_t)p + i);
-}
+    CR *row;            // element 0 of this trajectory's row (mode 0: any readable element -- the value is discarded)
+    int stride;         // 1: a value per grid point; 0: one value per trajectory
+    bool on;
+    // all of it wave-uniform and fixed for the trajectory: the grid loop pays one multiply-add, one load and one select per input --
+    // as a mode switch inside the loop it was four scalar branches per input and interval on the path between two steps
+    __device__ __forceinline__ UniformInput(const R *p, int mode, int b, int T, const R *any)
+        : row((CR *)(uintptr_t)(mode == 0 ? any : p) + (mode == 0 ? (size_t)0 : mode == 1 ? (size_t)b : (size_t)b * T)),
+          stride(mode == 2 ? 1 : 0), on(mode != 0) {}
+    __device__ __forceinline__ R at(int k) const
+    {
+        const R v = row[k * stride];
+        return on ? v : R(0);
+    }
+};
 
 template <typename R> struct Eps;
 template <> struct Eps<float> { static constexpr float v = 1.1920929e-7f; };
@@ -184,13 +193,14 @@ __device__ __forceinline__ void solve_one(const SolveArgs<R> &a, const int b, co
     // Grid point k + 2 is fetched at the top of interval k and first touched when interval k + 1 begins (every trajectory of the
     // benchmark takes ONE step per interval: fetched where they are used, the six loads of an interval and their full wait -- an L2
     // round trip, with the taping kernel's stores in the same queue -- opened every step of the integration; profiles/r04_pmc_fwd.log)
-    const int tb = a.t_batched ? b : 0;
+    const UniformInput<R> in_t(a.t, 2, a.t_batched ? b : 0, T, a.t), in_m(a.meal, a.meal_mode, b, T, a.t), in_v(a.tvns, a.tvns_mode, b, T, a.t),
+        in_d(a.gd, GD ? a.gd_mode : 0, b, T, a.t);
     auto grid_at = [&](int kk, R &tq, R &mq, R &vq, R &dq) {
         kk = kk < T ? kk : T - 1;
-        tq = inp_at_uniform(a.t, 2, tb, T, kk);
-        mq = inp_at_uniform(a.meal, a.meal_mode, b, T, kk);
-        vq = inp_at_uniform(a.tvns, a.tvns_mode, b, T, kk);
-        dq = GD ? inp_at_uniform(a.gd, a.gd_mode, b, T, kk) : R(0);
+        tq = in_t.at(kk);
+        mq = in_m.at(kk);
+        vq = in_v.at(kk);
+        dq = GD ? in_d.at(kk) : R(0);
     };
     R t0, m0, v0, d0, t1, m1, v1, d1, t2, m2, v2, d2;
     grid_at(0, t0, m0, v0, d0);
@@ -203,7 +213,14 @@ __device__ __forceinline__ void solve_one(const SolveArgs<R> &a, const int b, co
             y_put(Y);
             continue;
         }
-        const R inv_len = first_lane(R(1) / len);
+        // fp32: v_rcp_f32 + one Newton step (<= 1 ulp; the IEEE division is ten dependent instructions between two steps)
+        R inv_len;
+        if constexpr (sizeof(R) == 4) {
+            const float r0 = __builtin_amdgcn_rcpf(len);
+            inv_len = first_lane(__builtin_fmaf(__builtin_fmaf(-len, r0, 1.0f), r0, r0));
+        } else {
+            inv_len = first_lane(R(1) / len);
+        }
         const R dm = first_lane(m1 - m0), dv = first_lane(v1 - v0), dd = first_lane(d1 - d0);
         // piecewise-linear forcing on this interval (models/hybrid_ode_nn.py:217-229)
         // slot >= 0 (TAPE): also record the layer activations and the stage state for the adjoint
@@ -277,14 +294,17 @@ __device__ __forceinline__ void solve_one(const SolveArgs<R> &a, const int b, co
             while (tc < t1 && st == HODE_ST_OK) {
                 bool rejected = false;
                 for (;;) {                     // scipy/integrate/_ivp/rk.py:126-176
-                    if (ns >= a.max_steps) { st = HODE_ST_MAXSTEPS; break; }
-                    const R min_step = R(10) * Eps<R>::v * (rabs(tc) > R(1e-30) ? rabs(tc) : R(1e-30));
-                    if (h_abs < min_step) { st = HODE_ST_UNDERFLOW; break; }
-                    R h = h_abs, tn = tc + h;
-                    bool clipped = false;
-                    if (tn >= t1 || (t1 - tn) < R(0.01) * h) { tn = t1; h = tn - tc; clipped = true; }
-                    h = first_lane(h);
-                    tn = first_lane(tn);
+                    // (between two steps the wave is ONE dependent chain of wave-uniform decisions, each a vector compare -> scalar
+                    //  branch round trip, while its SIMD partner has the pipe to itself (profiles/r04_fwd_trace.log): the two exits share one
+                    //  branch and the clip is a select -- `|`, not `||`: no branch between the two comparisons)
+                    const R atc = rabs(tc);
+                    const R min_step = R(10) * Eps<R>::v * (atc > R(1e-30) ? atc : R(1e-30));
+                    const bool out_of_steps = ns >= a.max_steps;
+                    if (out_of_steps | (h_abs < min_step)) { st = out_of_steps ? HODE_ST_MAXSTEPS : HODE_ST_UNDERFLOW; break; }
+                    const R tn_free = tc + h_abs;
+                    const bool clipped = (tn_free >= t1) | ((t1 - tn_free) < R(0.01) * h_abs);
+                    const R tn = first_lane(clipped ? t1 : tn_free);
+                    const R h = first_lane(clipped ? t1 - tc : h_abs);
                     const bool fsal_fits = ns + 1 < a.max_steps;
                     R Ys = Y, F = R(0), err;
                     if constexpr (kUnrolled) {
@@ -323,7 +343,11 @@ __device__ __forceinline__ void solve_one(const SolveArgs<R> &a, const int b, co
                     const R Yn = Ys;                      // 5th-order solution
                     nf += 6;
                     const R ymax = rabs(Y) > rabs(Yn) ? rabs(Y) : rabs(Yn);
-                    const R qe = (c8 < 6) ? rdiv(err, a.atol + ymax * a.rtol) : R(0);
+                    // (the quotient on all lanes, then the select: as one conditional expression hipcc builds an exec-masked region --
+                    //  save, branch, restore -- on the path between two steps)
+                    R qall = rdiv(err, a.atol + ymax * a.rtol);
+                    asm volatile("" : "+v"(qall));
+                    const R qe = (c8 < 6) ? qall : R(0);
                     float en = first_lane(rms6<R>((float)first_lane(oct_allsum(qe * qe))));   // scalar from here on
                     const float ysum = (float)first_lane(oct_allsum(Yn));
                     if (!(en == en) || !(fabsf(ysum) <= 3.0e38f) || !(fabsf(en) <= 3.0e38f)) en = 1e30f;
@@ -348,9 +372,13 @@ __device__ __forceinline__ void solve_one(const SolveArgs<R> &a, const int b, co
             }
         }
         if (st == HODE_ST_OK) {
-            const float ysum = (float)first_lane(oct_allsum(Y));
-            if (!(fabsf(ysum) <= 3.0e38f)) st = HODE_ST_NONFINITE;
-            else y_put(Y);
+            if constexpr (METHOD == HODE_METHOD_RK4) {
+                const float ysum = (float)first_lane(oct_allsum(Y));
+                if (!(fabsf(ysum) <= 3.0e38f)) st = HODE_ST_NONFINITE;
+                else y_put(Y);
+            } else {
+                y_put(Y);        // DP5(4): Y is the result of an ACCEPTED step, and a step with a non-finite result is never accepted (en = 1e30)
+            }
         }
         if (st != HODE_ST_OK) break;
     }

@@ -48,6 +48,7 @@ static void launch_one(hipStream_t s, const SolveArgs<R> &a)
     constexpr int LB = (sizeof(R) == 4) ? (NL >= 3 ? 2 : (NL == 2 ? 3 : 4)) : 1;
     if constexpr (!TAPE && !GD && METHOD == HODE_METHOD_DP54 && sizeof(R) == 4) {
         // grid points <= 4, one parameter set, more trajectories than four rounds of the chip's 2 048 wave slots: see the kernel
+        // (the benchmark batch as ONE round of 2 048 waves with two trajectories each was measured too: 3.10 against 3.01 ms)
         if (a.T <= 4 && a.n_sets == 1 && a.B > 8192) {
             const int chunk = (a.B + 8191) / 8192;
             hipLaunchKernelGGL((solve_fwd_kernel<R, NL, METHOD, LB, TAPE, GD, true>), dim3((a.B + chunk - 1) / chunk), dim3(64), 0, s, a, chunk);
@@ -109,3 +110,12 @@ template int launch_solve_fwd<float>(hipStream_t, const SolveArgs<float> &, int,
 template int launch_solve_fwd<double>(hipStream_t, const SolveArgs<double> &, int, int);
 
 }  // namespace hode
+
+#ifdef HODE_FWD_TRACE
+// experiment build only: the stamps of hode_device.h's g_ft (this translation unit's copy: the forward kernels are instantiated here)
+extern "C" int hode_lab_fwd_trace(unsigned long long *dst, int n_words, unsigned *count)
+{
+    if (hipMemcpyFromSymbol(count, HIP_SYMBOL(hode::g_ft_n), sizeof(unsigned)) != hipSuccess) return -1;
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(hode::g_ft), sizeof(unsigned long long) * (size_t)n_words) == hipSuccess ? 0 : -1;
+}
+#endif

@@ -43,7 +43,10 @@ def test_library_exports_every_declared_symbol():
     assert hode.load().hode_tape_bytes(4096, 300, 4, 4) == 4096 * 300 * 36 + 4096 * 300 * 6 * (4 * 64 + 8) * 4 + 1024 * row * 4
     assert hode.load().hode_tape_bytes(4096, 300, 8, 4) == 4096 * 300 * 68 + 4096 * 300 * 6 * (4 * 64 + 8) * 8 + 1024 * row * 8
     assert hode.load().hode_tape_bytes(64, 300, 4, 4) == 64 * 300 * 36 + 64 * 300 * 6 * (4 * 64 + 8) * 4 + 64 * row * 4
-    assert hode.load().hode_tape_bytes_hl(64, 300, 4, 128, 5) == 64 * 300 * 36 + 64 * 300 * 6 * (2 * 5 * 64 + 8) * 4      # generic path: no rows
+    # generic path: fp32 leaves its gradients as rows too since round 4 (deterministic reduction); fp64 keeps atomics: no rows
+    row_g = (lib.hode_nn_param_count(128, 5) + 17 + 63) // 64 * 64
+    assert hode.load().hode_tape_bytes_hl(64, 300, 4, 128, 5) == 64 * 300 * 36 + 64 * 300 * 6 * (2 * 5 * 64 + 8) * 4 + 64 * row_g * 4
+    assert hode.load().hode_tape_bytes_hl(64, 300, 8, 128, 5) == 64 * 300 * 68 + 64 * 300 * 6 * (2 * 5 * 64 + 8) * 8
 
 
 def test_argument_validation_without_gpu():

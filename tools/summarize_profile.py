@@ -25,7 +25,7 @@ if len(stats) > 1:
              "the run, or the stale files -- the counters of different kernel versions would be averaged together")
 rows = list(csv.DictReader(open(stats[-1])))
 with open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w") as f:
-    f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 5 --train-steps 5 --no-cpu-baseline --no-vi --no-generic --no-zscore --no-build\n")
+    f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 40 --warmup 5 --train-steps 20 --no-cpu-baseline --no-vi --no-generic --no-zscore --no-sobol --no-class-path --no-build\n")
     f.write("kernel,calls,total_ns,avg_ns,pct,min_ns,max_ns\n")
     for r in rows[:18]:
         f.write(f"\"{short(r['Name'])[:90]}\",{r['Calls']},{r['TotalDurationNs']},{float(r['AverageNs']):.0f},{r['Percentage']},{r['MinNs']},{r['MaxNs']}\n")
@@ -70,6 +70,17 @@ for k, d in pmc.items():
         for key in ("fourgi_generate", "win_moment", "win_emit"):      # data side (bench.py "data_side" leg)
             if key in k:
                 traffic[f"{key}_hbm_bytes_per_launch"] = d["hbm_bytes_per_launch_corrected"]
+# derived figures for the solve kernels (what VERDICT r3 item 1 asks for): how busy the SIMDs' vector pipes are, what share of a wave's
+# life is spent waiting, what a vector instruction costs.  GRBM_GUI_ACTIVE is summed over the 8 XCDs; the chip has 1 024 SIMDs;
+# SQ_ACTIVE_INST_VALU counts in units of 4 cycles.
+for k, d in pmc.items():
+    if all(c in d for c in ("SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE", "SQ_WAIT_ANY", "SQ_WAVE_CYCLES", "SQ_INSTS_VALU")) and d["GRBM_GUI_ACTIVE"] > 0:
+        cyc = d["GRBM_GUI_ACTIVE"] / 8.0
+        d["derived"] = {"kernel_cycles": cyc,
+                        "valu_busy": 4.0 * d["SQ_ACTIVE_INST_VALU"] / (1024.0 * cyc),
+                        "wait_any_share_of_wave_cycles": d["SQ_WAIT_ANY"] / d["SQ_WAVE_CYCLES"],
+                        "pipe_cycles_per_valu_instruction": 4.0 * d["SQ_ACTIVE_INST_VALU"] / d["SQ_INSTS_VALU"],
+                        "valu_instructions_per_wave": d["SQ_INSTS_VALU"] / d["SQ_WAVES"] if d.get("SQ_WAVES") else None}
 json.dump(out, open(os.path.join(dst, f"{tag}_pmc.json"), "w"), indent=1)
 traffic["source"] = f"profiles/{tag}_pmc.json (2*FETCH_SIZE + WRITE_SIZE) KiB per launch"
 traffic["workloads"] = {"solve_*": "B=4096 T=241 fp32 (bench.py headline / train legs)",
