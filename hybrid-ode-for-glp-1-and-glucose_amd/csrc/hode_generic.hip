@@ -341,6 +341,7 @@ template <typename R, int NW = 1, typename EW = EdgeFromParams<R>, int CC = 16, 
     int part;               // this wave's index in its team (NW > 1: hode_generic.hip solve_fwd_generic_kernel)
     R *xch;                 // the team's exchange area (column split: partial sums; row split: hb[2][128])
     RowWeights<R, CC, NB> rw;   // row split with NB > 0: this wave's rows of the hidden matrices (rows_preload)
+    static constexpr bool kUnrollStages = false;
     __device__ __forceinline__ int slot_elems() const { return 2 * n.L * kWave + 8; }
     __device__ __forceinline__ R operator()(R ts, R Ys, R meal, R tvns, R gde, R *__restrict__ rec) const
     {
@@ -349,6 +350,117 @@ template <typename R, int NW = 1, typename EW = EdgeFromParams<R>, int CC = 16, 
             if (n.L >= 2) return rhs_rows<R, NW, EW, CC, NB>(n, ew, rw, o, ts, Ys, meal, tvns, gde, lane, part == 0 ? rec : nullptr, part, xch);
         }
         return rhs_stream<R, NW, EW>(n, ew, o, ts, Ys, meal, tvns, gde, lane, part == 0 ? rec : nullptr, part, xch);
+    }
+};
+
+// ---- SEVERAL trajectories per team (solve_fwd_generic_multi_kernel; fp32, register-resident rows) ------------------------------------
+// rhs_rows gives a whole team to ONE trajectory: every wave repeats the integrator, the first and the output layer, and a layer costs a
+// barrier per trajectory; above a few hundred trajectories the teams stream the hidden matrices from L2 instead of keeping them (262 KB
+// per evaluation for 5 x 128: 17 TB/s at 1 024 x 61, the bound of that launch).  Here a workgroup of eight waves serves TB trajectories:
+// wave w INTEGRATES trajectory w % TB (controller, first layer, output layer, tape: once per trajectory, not once per wave) and owns its
+// row blocks of every hidden matrix in registers FOR ALL of them -- per layer one barrier, TB x (4 LDS reads of 16 bytes + 32 FMAs + the
+// 8-lane sums).  The trajectories of a team need not be in step: a round is "every wave has published the first-layer output of its
+// next evaluation", whatever stage, step or grid interval that evaluation belongs to.  A wave whose trajectory is finished (or that has
+// none) keeps serving rounds until all are (done counter in LDS, read behind the round's first barrier by the waves that are serving:
+// they all see the same value and leave together).
+template <int TB, int CC, int NB> struct RhsMulti {
+    static constexpr int kNW = 8;
+    StreamNet<float> n;
+    EdgeImage<float> ew;
+    const OdeP<float> &o;
+    int lane, part;
+    float *hbm;                  // [TB][3][kHbStride] activation vectors (zero beyond H): h_1 in buffer 2, h_{l+2} in buffer l & 1 -- the
+                                 // first layer of a trajectory's NEXT evaluation never writes what a slower wave still reads
+    RowWeights<float, CC, NB> rw;
+    static constexpr bool kUnrollStages = false;
+    __device__ __forceinline__ int slot_elems() const { return 2 * n.L * kWave + 8; }
+    // the hidden layers of one round for all TB trajectories; barriers: one behind every layer.  rec != nullptr: this wave's own
+    // trajectory is being taped -- h_{l+1} is copied out of LDS right behind the layer's barrier (the buffer is next written two
+    // layers on, behind a barrier this wave has not passed yet)
+    __device__ __forceinline__ void layers(float *__restrict__ rec) const
+    {
+        const float *__restrict__ hb_own = hbm + (part % TB) * 3 * kHbStride;
+        const int H = n.H, L = n.L;
+        const int c8 = lane & 7, r8 = lane >> 3, k0 = CC * c8;
+        auto layer = [&](const int l, auto slot) {
+            float bias[NB > 0 ? NB : 1];
+#pragma unroll
+            for (int blk = 0; blk < NB; ++blk) {
+                const int row = 8 * (part + kNW * blk) + r8;
+                bias[blk] = ew.bh(l)[row < H ? row : 0];
+            }
+#pragma unroll 2
+            for (int tt = 0; tt < TB; ++tt) {
+                const float *__restrict__ hin = hbm + (tt * 3 + (l == 0 ? 2 : (l - 1) & 1)) * kHbStride;
+                float *__restrict__ hout = hbm + (tt * 3 + (l & 1)) * kHbStride;
+                float hc[CC];
+#pragma unroll
+                for (int u = 0; u < CC; ++u) hc[u] = hin[hx<CC>(k0) + u];
+#pragma unroll
+                for (int blk = 0; blk < NB; ++blk) {
+                    const int row = 8 * (part + kNW * blk) + r8;
+                    float acc = 0.f;
+#pragma unroll
+                    for (int u = 0; u < CC; ++u) acc = rfma(rw.w[decltype(slot)::value][blk][u], hc[u], acc);
+                    acc = oct_allsum(acc);
+                    const float v = act_f(acc + bias[blk], n.act);
+                    if (c8 == 0 && row < H) hout[hx<CC>(row)] = v;
+                }
+            }
+            __syncthreads();
+            if (rec) {
+                const float *__restrict__ ho = hb_own + (l & 1) * kHbStride;
+                rec[(2 * (l + 1)) * kWave + lane] = ho[hx<CC>(lane)];
+                rec[(2 * (l + 1) + 1) * kWave + lane] = ho[hx<CC>(kWave + lane)];
+            }
+        };
+#pragma unroll
+        for (int i = 0; i < kGenAccMats; ++i) {
+            if (i + 1 >= L) break;
+            if (i == 0) layer(0, std::integral_constant<int, 0>{});
+            else if (i == 1) layer(1, std::integral_constant<int, 1>{});
+            else if (i == 2) layer(2, std::integral_constant<int, 2>{});
+            else layer(3, std::integral_constant<int, 3>{});
+        }
+    }
+    __device__ __forceinline__ float operator()(float t, float Y, float meal, float tvns, float gde, float *__restrict__ rec) const
+    {
+        const int H = n.H, L = n.L;
+        rec = part < TB ? rec : nullptr;                    // (TB < 8: waves w and w + TB integrate the same trajectory; one writes)
+        float *__restrict__ hb = hbm + (part % TB) * 3 * kHbStride;
+        const float G = lane_bcast(Y, 0), I = lane_bcast(Y, 1), Glu = lane_bcast(Y, 2), GLP1 = lane_bcast(Y, 3), GE = lane_bcast(Y, 4),
+                    FFA = lane_bcast(Y, 5);
+        const int c8 = lane & 7, r8 = lane >> 3;
+        const float mech = mech_eval(o, G, I, Glu, GLP1, FFA, meal, gde, c8);
+        const bool vA = lane < H, vB = lane + 64 < H;
+        const int jA = vA ? lane : 0, jB = vB ? lane + 64 : 0;
+        const float in[9] = {t, G, I, Glu, GLP1, GE, FFA, GLP1, tvns};          // models/nn_residual.py:138-143
+        float hA = ew.b1()[jA], hB = ew.b1()[jB];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            hA = rfma(ew.W1()[jA * 9 + i], in[i], hA);
+            hB = rfma(ew.W1()[jB * 9 + i], in[i], hB);
+        }
+        hA = vA ? act_f(hA, n.act) : 0.f;
+        hB = vB ? act_f(hB, n.act) : 0.f;
+        hb[2 * kHbStride + hx<CC>(lane)] = hA;
+        hb[2 * kHbStride + hx<CC>(kWave + lane)] = hB;
+        if (rec) { rec[lane] = hA; rec[kWave + lane] = hB; }
+        __syncthreads();                                    // the round's first barrier: every trajectory's h_1 is in LDS
+        layers(rec);
+        const float *__restrict__ hf = hb + (L >= 2 ? (L - 2) & 1 : 2) * kHbStride;
+        const int q = (c8 < 6) ? c8 : 0, ko = 16 * r8;
+        float acc = 0.f;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int k = ko + u;
+            acc = rfma((k < H) ? ew.Wo()[q * H + ((k < H) ? k : 0)] : 0.f, hf[hx<CC>(k)], acc);
+        }
+        acc = (c8 < 6) ? acc : 0.f;
+        const float nn = group_sum8(acc);
+        if (rec && lane < 8) rec[2 * L * kWave + lane] = Y;
+        const float bout = (c8 < 6) ? ew.bo()[q] : 0.f;
+        return (c8 < 6) ? (mech + nn + bout) : 0.f;
     }
 };
 
@@ -750,6 +862,57 @@ __global__ __launch_bounds__(64 * NW, (sizeof(R) == 8) ? 1 : (NB > 0 ? 2 : 4)) v
     solve_one<R, METHOD, TAPE, GD>(a, b, rhs, o, rows, cvec, ybuf + part * (kWave + 8), lane);
 }
 
+// TB trajectories per eight-wave workgroup (RhsMulti).  Launched for fp32, at most kGenAccMats hidden matrices, whole parameter sets
+// per workgroup (per_set % TB == 0).
+template <int METHOD, bool TAPE, bool GD, int TB, int CC, int NB>
+__global__ __launch_bounds__(512, 2) void solve_fwd_generic_multi_kernel(const SolveArgs<float> a)
+{
+    constexpr int NW = 8;
+    __shared__ float rows[8 * kWave];
+    __shared__ float cvec[8];
+    __shared__ float ybuf[NW * (kWave + 8)];
+    __shared__ float hbm[TB * 3 * kHbStride];
+    __shared__ float edge_img[kEdgeImageMax];
+    __shared__ int done_cnt;
+    const int lane = threadIdx.x & 63;
+    const int part = first_lane((int)(threadIdx.x >> 6));
+    const int b = blockIdx.x * TB + part % TB;
+    const int set = (blockIdx.x * TB) / (a.B / a.n_sets);
+    for (int i = threadIdx.x; i < TB * 3 * kHbStride; i += 64 * NW) hbm[i] = 0.f;
+    tableau_rows_store<float>(rows, METHOD, threadIdx.x, 64 * NW);
+    if (threadIdx.x < 8) cvec[threadIdx.x] = (float)kTableau[METHOD].c[threadIdx.x];
+    if (threadIdx.x == 0) done_cnt = 0;
+    OdeP<float> o;
+    ode_load(o, a.ode_p + 17 * set);
+    const StreamNet<float> net{a.nn_p + (size_t)set * a.nn_stride, a.H, a.L, a.act};
+    EdgeImage<float>::fill(edge_img, net, threadIdx.x, 64 * NW);
+    __syncthreads();
+    RhsMulti<TB, CC, NB> rhs{net, EdgeImage<float>{edge_img, a.H, a.L}, o, lane, part, hbm, {}};
+    rows_preload<float, NW, CC, NB>(rhs.rw, net, lane, part);
+    if (b < a.B) solve_one<float, METHOD, TAPE, GD>(a, b, rhs, o, rows, cvec, ybuf + part * (kWave + 8), lane);
+    // serve the other trajectories' rounds until every wave of the team is here
+    if (lane == 0) atomicAdd(&done_cnt, 1);
+    for (;;) {
+        __syncthreads();                                    // = the first barrier of a round
+        if (*(volatile int *)&done_cnt == NW) break;        // (nobody is integrating any more: every wave reads NW in the same round)
+        rhs.layers(nullptr);
+    }
+}
+
+template <int METHOD, int TB, int CC, int NB> static int launch_fwd_generic_multi(hipStream_t s, const SolveArgs<float> &a)
+{
+    const bool tape = a.tape != nullptr, gd = a.gd_mode != 0;
+    const dim3 grid((a.B + TB - 1) / TB), block(512);
+    if (tape) {
+        if (gd) hipLaunchKernelGGL((solve_fwd_generic_multi_kernel<METHOD, true, true, TB, CC, NB>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((solve_fwd_generic_multi_kernel<METHOD, true, false, TB, CC, NB>), grid, block, 0, s, a);
+    } else {
+        if (gd) hipLaunchKernelGGL((solve_fwd_generic_multi_kernel<METHOD, false, true, TB, CC, NB>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((solve_fwd_generic_multi_kernel<METHOD, false, false, TB, CC, NB>), grid, block, 0, s, a);
+    }
+    return hipGetLastError() == hipSuccess ? HODE_OK : HODE_ELAUNCH;
+}
+
 template <typename R, int METHOD, int NW, int CC = 16, int NB = 0> static int launch_fwd_generic_t(hipStream_t s, const SolveArgs<R> &a)
 {
     const bool tape = a.tape != nullptr, gd = a.gd_mode != 0;
@@ -775,6 +938,15 @@ template <typename R, int METHOD> static int launch_fwd_generic_m(hipStream_t s,
     if constexpr (sizeof(R) == 4) {
         if (a.L >= 2 && a.L - 1 <= kGenAccMats && a.B <= (narrow ? 256 : 512))
             return narrow ? launch_fwd_generic_t<R, METHOD, 8, 8, 1>(s, a) : launch_fwd_generic_t<R, METHOD, 8, 16, 2>(s, a);
+        // above that: several trajectories per team, rows still register-resident (four per team up to two workgroups per CU's worth of
+        // trajectories, eight beyond); needs whole parameter sets per workgroup
+        if (a.L >= 2 && a.L - 1 <= kGenAccMats) {
+            const int per_set = a.B / a.n_sets;
+            if (a.B >= 2048 && per_set % 8 == 0)
+                return narrow ? launch_fwd_generic_multi<METHOD, 8, 8, 1>(s, a) : launch_fwd_generic_multi<METHOD, 8, 16, 2>(s, a);
+            if (per_set % 4 == 0)
+                return narrow ? launch_fwd_generic_multi<METHOD, 4, 8, 1>(s, a) : launch_fwd_generic_multi<METHOD, 4, 16, 2>(s, a);
+        }
     }
     if (a.B <= 256) return narrow ? launch_fwd_generic_t<R, METHOD, 8, 8, 0>(s, a) : launch_fwd_generic_t<R, METHOD, 8, 16, 0>(s, a);
     return narrow ? launch_fwd_generic_t<R, METHOD, 4, 8, 0>(s, a) : launch_fwd_generic_t<R, METHOD, 4, 16, 0>(s, a);

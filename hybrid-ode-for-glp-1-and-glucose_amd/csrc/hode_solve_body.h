@@ -51,6 +51,7 @@ template <typename R, int NL, typename WT> struct RhsRegs {
     const OdeP<R> &o;
     int lane;
     static constexpr bool kKeep = true;
+    static constexpr bool kUnrollStages = true;      // solve_one: six copies of this right-hand side (~230 instructions each) are worth it
     // stage record of the tuned path: h_1 .. h_NL (rows of 64) | the 6-vector stage state in 8 reals (the replicated
     // 64-lane copy of the state would be another 256-byte row): 1 056 B per stage for (64,4) in fp32
     __device__ __forceinline__ int slot_elems() const { return NL * kWave + 8; }
@@ -186,7 +187,9 @@ __device__ __forceinline__ void solve_one(const SolveArgs<R> &a, const int b, co
     // fp32 DP5(4): the stages are unrolled and every stage derivative has a register of its own (replicated layout, like Y):
     // a stage combination is <= 6 FMAs with literal coefficients -- no packed register, no coefficient row from LDS, no 7-instruction
     // cross-lane sum, no slot select (12 vector instructions per stage in the rolled form, ~4.5 here).  KF = the FSAL derivative.
-    constexpr bool kUnrolled = METHOD == HODE_METHOD_DP54 && sizeof(R) == 4 && !GD;       // (the Hill term's two pow calls x 6 stages: scratch)
+    // (not with the Hill term: two pow calls x 6 stages end in scratch; not for the generic path's functors: six copies of a team's
+    //  layer loop are more code than the instruction cache holds)
+    constexpr bool kUnrolled = METHOD == HODE_METHOD_DP54 && sizeof(R) == 4 && !GD && RHS::kUnrollStages;
     R KF = R(0);
     bool have_f = false;
 

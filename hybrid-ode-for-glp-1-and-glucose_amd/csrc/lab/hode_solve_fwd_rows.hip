@@ -146,6 +146,7 @@ template <int NL> struct RhsRows {
     const MlpRows<NL> &W;
     const OdeP<float> &o;
     int lane;
+    static constexpr bool kUnrollStages = true;      // the arithmetic of the production kernel (bitwise comparisons)
     __device__ __forceinline__ int slot_elems() const { return NL * kWave + 8; }
     __device__ __forceinline__ float operator()(float ts, float Ys, float meal, float tvns, float gde, float *__restrict__ rec) const
     {
