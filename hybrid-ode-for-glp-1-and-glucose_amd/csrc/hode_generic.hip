@@ -1089,6 +1089,420 @@ __global__ __launch_bounds__(64 * kGenTeam) void solve_bwd_generic_kernel(const 
     }
 }
 
+// ------------------------------------------------------------------------------------------ K4, several trajectories per team
+// The adjoint of RhsMulti's idea (fp32, at most kGenAccMats hidden matrices, gradient rows).  solve_bwd_generic_kernel gives the whole
+// team to ONE trajectory: eight waves walk the same tape, every stage streams every hidden matrix from L2 once PER TRAJECTORY and pays a
+// barrier per layer and trajectory.  Here wave w walks the tape of trajectory w % TB of the team's current group -- step headers,
+// cotangent injection, the mechanistic and edge-layer VJPs once per trajectory, not once per wave -- and for every hidden matrix the
+// owners publish delta_{l+1} and h_l of their trajectories in LDS, every wave multiplies ITS rows (streamed from L2 ONCE per round) with
+// all TB cotangents and adds its rows of dW += delta (x) h for all of them, the partial sums go back through LDS to the owners: two
+// barriers per matrix and ROUND.  A round = one stage of every trajectory that still has one; a wave whose tape is exhausted zeroes its
+// published vectors (its products and outer products are then exact zeros) and serves until the group is done.
+constexpr int kMultiEdgeVals = 17;      // eo 0..5 (output matrix rows) | ei 6..14 (first matrix columns) | 15 its bias | 16 output bias
+template <int RPW> struct MultiAcc {
+    float m0[RPW][2], m1[RPW][2], m2[RPW][2], m3[RPW][2];      // this wave's rows of dW of up to four hidden matrices (slot 0 = the LAST)
+    // The edge gradients of the trajectories THIS wave walks (units lane, lane + 64).  Sixteen rows per wave (H > 64) are 128
+    // accumulator registers: 34 more do not fit next to them (540 spill instructions, measured) -- those teams keep the edge sums in a
+    // wave-private LDS table [value][2][64] and pay 17 independent read-add-write pairs per stage; eight-row teams keep registers.
+    static constexpr bool kEdgeLds = RPW > 8;
+    float e[kEdgeLds ? 1 : kMultiEdgeVals][2];
+    float *eld;
+    float eb[2];                 // wave 3 + i: the bias of the hidden matrix in slot i, for ALL trajectories (from the published cotangents)
+    __device__ __forceinline__ void zero(float *eld_own, int lane)
+    {
+#pragma unroll
+        for (int u = 0; u < RPW; ++u) m0[u][0] = m0[u][1] = m1[u][0] = m1[u][1] = m2[u][0] = m2[u][1] = m3[u][0] = m3[u][1] = 0.f;
+        eld = eld_own;
+        if constexpr (kEdgeLds) {
+            for (int v = 0; v < kMultiEdgeVals * 2; ++v) eld[v * kWave + lane] = 0.f;
+        } else {
+#pragma unroll
+            for (int v = 0; v < kMultiEdgeVals; ++v) e[v][0] = e[v][1] = 0.f;
+        }
+        eb[0] = eb[1] = 0.f;
+    }
+    template <int V> __device__ __forceinline__ void edge_add(float x0, float x1, int lane)
+    {
+        if constexpr (kEdgeLds) {
+            float *__restrict__ q = eld + (V * 2) * kWave + lane;
+            q[0] += x0;
+            q[kWave] += x1;
+        } else {
+            e[V][0] += x0;
+            e[V][1] += x1;
+        }
+    }
+    // (a sum of products as one FMA per half in the register form -- the same bits either way is not promised between the two forms)
+    template <int V> __device__ __forceinline__ void edge_fma(float a0, float b0, float a1, float b1, int lane)
+    {
+        if constexpr (kEdgeLds) {
+            float *__restrict__ q = eld + (V * 2) * kWave + lane;
+            q[0] = rfma(a0, b0, q[0]);
+            q[kWave] = rfma(a1, b1, q[kWave]);
+        } else {
+            e[V][0] = rfma(a0, b0, e[V][0]);
+            e[V][1] = rfma(a1, b1, e[V][1]);
+        }
+    }
+    __device__ __forceinline__ float edge_get(int v, int half, int lane) const
+    {
+        if constexpr (kEdgeLds) return eld[(v * 2 + half) * kWave + lane];
+        else return e[v][half];
+    }
+    template <int SLOT> __device__ __forceinline__ void fma(int u, float dj, float inA, float inB)
+    {
+        float(&m)[RPW][2] = SLOT == 0 ? m0 : SLOT == 1 ? m1 : SLOT == 2 ? m2 : m3;
+        m[u][0] = __builtin_fmaf(dj, inA, m[u][0]);
+        m[u][1] = __builtin_fmaf(dj, inB, m[u][1]);
+    }
+    __device__ __forceinline__ void store_one(const float (&m)[RPW][2], float *__restrict__ gW, int H, int j0, int lane) const
+    {
+#pragma unroll
+        for (int u = 0; u < RPW; ++u) {
+            const int j = j0 + u;
+            if (j < H) {
+                if (lane < H) gW[(size_t)j * H + lane] = m[u][0];
+                if (lane + 64 < H) gW[(size_t)j * H + lane + 64] = m[u][1];
+            }
+        }
+    }
+};
+
+// one hidden matrix of a round: this wave's rows of W^T delta and of dW for all TB published trajectories.  Between the round's two
+// barriers of this matrix (the caller places them).
+template <int TB, int RPW, int SLOT>
+__device__ __forceinline__ void multi_team_matrix(const StreamNet<float> &n, const int l, MultiAcc<RPW> &acc, const float *__restrict__ dl,
+                                                  const float *__restrict__ hin, float *__restrict__ xl, int lane, int part, bool want_g)
+{
+    constexpr int NW = 8;
+    const int H = n.H;
+    const int j0 = part * RPW;                                 // this wave's rows [j0, j0 + RPW) (rows beyond H: zero cotangents)
+    const float *W = n.Wh(l);
+    const bool vA = lane < H, vB = lane + 64 < H;
+    const unsigned oA = (unsigned)(vA ? lane : 0) * 4u, oB = (unsigned)(vB ? lane + 64 : 0) * 4u;
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(W), 0, (int)((unsigned)H * (unsigned)H * 4u), 0x00020000);
+    // eight rows at a time stay in registers while a RUN-TIME loop walks the trajectories (unrolled over them, hipcc hoists every load of
+    // every trajectory and spills a thousand registers); a trajectory's partial sums of the second chunk are added to the first's in LDS
+#pragma unroll
+    for (int c = 0; c < RPW / 8; ++c) {
+        float wA[8], wB[8];
+        // (rows at or beyond H: the buffer load is out of range and returns 0)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const unsigned roff = (unsigned)(j0 + 8 * c + u) * (unsigned)H * 4u;
+            wA[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)oA, (int)roff, 0));
+            wB[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)oB, (int)roff, 0));
+        }
+#pragma unroll 1
+        for (int tt = 0; tt < TB; ++tt) {
+            float dj[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) dj[u] = dl[tt * 2 * kWave + j0 + 8 * c + u];      // wave-uniform address: a broadcast read
+            float *__restrict__ xa = xl + ((tt * NW + part) * 2 + 0) * kWave + lane, *__restrict__ xb = xa + kWave;
+            float pA = (c == 0) ? 0.f : *xa, pB = (c == 0) ? 0.f : *xb;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                pA = rfma(wA[u], dj[u], pA);
+                pB = rfma(wB[u], dj[u], pB);
+            }
+            *xa = vA ? pA : 0.f;
+            *xb = vB ? pB : 0.f;
+            if (want_g) {
+                const float inA = hin[tt * 2 * kWave + lane], inB = hin[tt * 2 * kWave + kWave + lane];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc.template fma<SLOT>(8 * c + u, dj[u], inA, inB);
+            }
+        }
+    }
+    // the bias of this matrix: its gradient is the sum of the published cotangents -- wave 3 + SLOT adds them for all trajectories
+    if (want_g && part == 3 + SLOT) {
+#pragma unroll 1
+        for (int tt = 0; tt < TB; ++tt) { acc.eb[0] += dl[tt * 2 * kWave + lane]; acc.eb[1] += dl[tt * 2 * kWave + kWave + lane]; }
+    }
+}
+
+// the hidden matrices of one round as a SERVING wave sees them (its own trajectory is finished): the round's first barrier has been
+// passed by the caller
+template <int TB, int RPW>
+__device__ __forceinline__ void multi_serve_round(const StreamNet<float> &n, MultiAcc<RPW> &acc, const float *__restrict__ dl,
+                                                  const float *__restrict__ hin, float *__restrict__ xl, int lane, int part, bool want_g)
+{
+    const int L = n.L;
+#pragma unroll
+    for (int i = 0; i < kGenAccMats; ++i) {
+        if (i > L - 2) break;
+        if (i > 0) __syncthreads();
+        if (i == 0) multi_team_matrix<TB, RPW, 0>(n, L - 2, acc, dl, hin, xl, lane, part, want_g);
+        else if (i == 1) multi_team_matrix<TB, RPW, 1>(n, L - 3, acc, dl, hin, xl, lane, part, want_g);
+        else if (i == 2) multi_team_matrix<TB, RPW, 2>(n, L - 4, acc, dl, hin, xl, lane, part, want_g);
+        else multi_team_matrix<TB, RPW, 3>(n, L - 5, acc, dl, hin, xl, lane, part, want_g);
+        __syncthreads();
+    }
+}
+
+// J^T kb of ONE stage of this wave's own trajectory, the hidden matrices as team rounds (see above).  own = this wave accumulates the
+// edge gradients of its trajectory (false for the second wave of a trajectory when TB < 8).
+template <bool GODE, int TB, int RPW>
+__device__ __forceinline__ float rhs_vjp_multi(const StreamNet<float> &n, const EdgeImage<float> &ew, const OdeP<float> &o, float t, float tvns,
+                                               float gde, float gd_in, bool use_gd, int lane, const float *__restrict__ rec, float kb, float &go,
+                                               int part, MultiAcc<RPW> &acc, float *__restrict__ dl, float *__restrict__ hin,
+                                               float *__restrict__ xl, bool want_g, bool own)
+{
+    constexpr int NW = 8;
+    const int H = n.H, L = n.L, ts = part % TB;
+    const float *__restrict__ sx = rec + 2 * L * kWave;
+    const float G = sx[0], I = sx[1], Glu = sx[2], GLP1 = sx[3], GE = sx[4], FFA = sx[5];
+    const float lq[6] = {lane_bcast(kb, 0), lane_bcast(kb, 1), lane_bcast(kb, 2), lane_bcast(kb, 3), lane_bcast(kb, 4), lane_bcast(kb, 5)};
+    const int c8 = lane & 7;
+    const float mech = mech_vjp<float, GODE>(o, G, I, Glu, GLP1, FFA, lq[0], lq[1], lq[2], lq[3], lq[5], gde, gd_in, use_gd, lane, go);
+    const bool vA = lane < H, vB = lane + 64 < H;
+    const int jA = vA ? lane : 0, jB = vB ? lane + 64 : 0;
+    const bool eg = want_g && own;
+    // output layer
+    float hA = rec[(2 * (L - 1)) * kWave + lane], hB = rec[(2 * (L - 1) + 1) * kWave + lane];
+    float dA = 0.f, dB = 0.f;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        dA = rfma(ew.Wo()[q * H + jA], lq[q], dA);
+        dB = rfma(ew.Wo()[q * H + jB], lq[q], dB);
+    }
+    if (eg) {
+        acc.template edge_fma<0>(lq[0], hA, lq[0], hB, lane); acc.template edge_fma<1>(lq[1], hA, lq[1], hB, lane);
+        acc.template edge_fma<2>(lq[2], hA, lq[2], hB, lane); acc.template edge_fma<3>(lq[3], hA, lq[3], hB, lane);
+        acc.template edge_fma<4>(lq[4], hA, lq[4], hB, lane); acc.template edge_fma<5>(lq[5], hA, lq[5], hB, lane);
+        acc.template edge_add<16>(kb, 0.f, lane);             // lanes 0..5 carry the six components
+    }
+    dA = vA ? act_bwd(dA, hA, n.act) : 0.f;
+    dB = vB ? act_bwd(dB, hB, n.act) : 0.f;
+    auto hidden = [&](const int l, auto slot) {
+        constexpr int SLOT = decltype(slot)::value;
+        const float inA = rec[(2 * l) * kWave + lane], inB = rec[(2 * l + 1) * kWave + lane];
+        dl[ts * 2 * kWave + lane] = dA;
+        dl[ts * 2 * kWave + kWave + lane] = dB;
+        hin[ts * 2 * kWave + lane] = vA ? inA : 0.f;
+        hin[ts * 2 * kWave + kWave + lane] = vB ? inB : 0.f;
+        __syncthreads();                                       // every trajectory's delta_{l+1} and h_l are published
+        multi_team_matrix<TB, RPW, SLOT>(n, l, acc, dl, hin, xl, lane, part, want_g);
+        __syncthreads();                                       // every wave's partial sums are in xl
+        float pA = 0.f, pB = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) { pA += xl[((ts * NW + w) * 2 + 0) * kWave + lane]; pB += xl[((ts * NW + w) * 2 + 1) * kWave + lane]; }
+        dA = vA ? act_bwd(pA, inA, n.act) : 0.f;
+        dB = vB ? act_bwd(pB, inB, n.act) : 0.f;
+    };
+#pragma unroll
+    for (int i = 0; i < kGenAccMats; ++i) {
+        if (i > L - 2) break;
+        if (i == 0) hidden(L - 2, std::integral_constant<int, 0>{});
+        else if (i == 1) hidden(L - 3, std::integral_constant<int, 1>{});
+        else if (i == 2) hidden(L - 4, std::integral_constant<int, 2>{});
+        else hidden(L - 5, std::integral_constant<int, 3>{});
+    }
+    // first layer
+    const float in[9] = {t, G, I, Glu, GLP1, GE, FFA, GLP1, tvns};
+    if (eg) {
+        acc.template edge_fma<6>(dA, in[0], dB, in[0], lane); acc.template edge_fma<7>(dA, in[1], dB, in[1], lane);
+        acc.template edge_fma<8>(dA, in[2], dB, in[2], lane); acc.template edge_fma<9>(dA, in[3], dB, in[3], lane);
+        acc.template edge_fma<10>(dA, in[4], dB, in[4], lane); acc.template edge_fma<11>(dA, in[5], dB, in[5], lane);
+        acc.template edge_fma<12>(dA, in[6], dB, in[6], lane); acc.template edge_fma<13>(dA, in[7], dB, in[7], lane);
+        acc.template edge_fma<14>(dA, in[8], dB, in[8], lane);
+        acc.template edge_add<15>(dA, dB, lane);
+    }
+    float w[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) w[i] = ew.W1()[jA * 9 + i] * dA + ew.W1()[jB * 9 + i] * dB;
+    const float p[6] = {w[1], w[2], w[3], w[4] + w[7], w[5], w[6]};
+    const float nn = wave_reduce6_to_lanes(p, lane);
+    return (c8 < 6) ? (mech + nn) : 0.f;
+}
+
+template <bool GODE, bool GD, int TB, int RPW>
+__global__ __launch_bounds__(512, 2) void solve_bwd_generic_multi_kernel(const AdjArgs<float> a, const int method, const int L)
+{
+    constexpr int NW = 8;
+    MultiAcc<RPW> acc;
+    __shared__ float rowsT[8 * kWave];
+    __shared__ float eld_all[(MultiAcc<RPW>::kEdgeLds ? TB : 1) * kMultiEdgeVals * 2 * kWave];     // the walking waves' edge sums (H > 64)
+    __shared__ float edge_img[kEdgeImageMax];
+    __shared__ float dl[TB * 2 * kWave], hin[TB * 2 * kWave];
+    __shared__ float xl[TB * NW * 2 * kWave];
+    __shared__ int done_cnt;
+    const int lane = threadIdx.x & 63;
+    const int part = first_lane((int)(threadIdx.x >> 6));
+    const int c8 = lane & 7, grp = lane >> 3;
+    const int T = a.T, ts = part % TB;
+    const bool own = part < TB;
+    acc.zero(eld_all + (MultiAcc<RPW>::kEdgeLds && own ? part : 0) * kMultiEdgeVals * 2 * kWave, lane);      // (only walking waves touch it)
+    const TableauData &tab = kTableau[method];
+    const int S = tab.S;
+    const int kSlot = 2 * L * kWave + 8;
+    const int per_set = a.B / a.n_sets, set = blockIdx.y;
+    const StreamNet<float> n{a.nn_p + (size_t)set * a.P, a.H, L, a.act};
+    const bool want_g = a.gnn != nullptr;
+    tableau_rowsT_store<float>(rowsT, method, threadIdx.x, 64 * NW);
+    EdgeImage<float>::fill(edge_img, n, threadIdx.x, 64 * NW);
+    const size_t rowlen = adj_partial_rowlen(a.P);
+    float *__restrict__ prow = a.partials + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * rowlen;
+    for (size_t i = threadIdx.x; i < rowlen; i += 64 * NW) prow[i] = 0.f;
+    const EdgeImage<float> ew{edge_img, a.H, L};
+    OdeP<float> o;
+    ode_load(o, a.ode_p + 17 * set);
+    constexpr bool use_gd = GD;
+    float go_sum = 0.f;
+    const int groups = (per_set + TB - 1) / TB;
+    for (int g = blockIdx.x; g < groups; g += gridDim.x) {
+        for (int i = threadIdx.x; i < TB * 2 * kWave; i += 64 * NW) { dl[i] = 0.f; hin[i] = 0.f; }
+        if (threadIdx.x == 0) done_cnt = 0;
+        __syncthreads();
+        const int bi = g * TB + ts;
+        if (bi < per_set) {
+            const int b = set * per_set + bi;
+            const float *__restrict__ tg = a.t + (a.t_batched ? (size_t)b * T : 0);
+            const float *__restrict__ tape = a.tape + (size_t)b * a.max_steps * 8;
+            const int *__restrict__ tseg = a.tape_seg + (size_t)b * a.max_steps;
+            const float *__restrict__ stg = a.tape_stage + (size_t)b * a.max_steps * 6 * kSlot;
+            const float *__restrict__ gyb = a.gy + (size_t)b * T * 6;
+            const int nst = a.nsteps[b] < a.max_steps ? a.nsteps[b] : a.max_steps;
+            const bool ok = a.status[b] == HODE_ST_OK;
+            auto gy_row = [&](int r) -> float { return (c8 < 6) ? gyb[(size_t)r * 6 + c8] : 0.f; };
+            float lam = 0.f, go = 0.f;
+            int knext = T - 1;
+            for (int st = nst - 1; st >= 0; --st) {
+                const int kraw = tseg[st];
+                const int k = kraw & (kSegClosed - 1);
+                int hi = knext;                               // rows this step produced: see solve_bwd_kernel
+                if (st == nst - 1) {
+                    hi = T - 1;
+                    if (!ok) {
+                        hi = k;
+                        if (kraw & kSegClosed) {
+                            hi = k + 1;
+                            while (hi + 1 < T && !(tg[hi + 1] > tg[hi])) ++hi;
+                        }
+                    }
+                }
+                for (int r = k + 1; r <= hi; ++r) lam += gy_row(r);
+                knext = k;
+                // the step header as the forward wrote it: {t, h, t0, 1 / (t1 - t0), v0, dv, d0, dd}
+                const float tc = tape[(size_t)st * 8 + 0], h = tape[(size_t)st * 8 + 1], t0 = tape[(size_t)st * 8 + 2], inv_len = tape[(size_t)st * 8 + 3];
+                const float v0 = tape[(size_t)st * 8 + 4], dv = tape[(size_t)st * 8 + 5], d0 = tape[(size_t)st * 8 + 6], dd = tape[(size_t)st * 8 + 7];
+                float ZZ = 0.f;
+                for (int s = S - 1; s >= 0; --s) {
+                    const float bw_s = rowsT[6 * kWave + s], c_s = rowsT[6 * kWave + 8 + s];
+                    const float kb = h * rfma(bw_s, lam, group_sum8(rowsT[s * kWave + lane] * ZZ));
+                    const float tst = rfma(c_s, h, tc);
+                    const float al = (tst - t0) * inv_len;
+                    const float gdv = rfma(al, dd, d0);
+                    float gde = 0.f;
+                    if constexpr (use_gd) gde = gd_effect(o, gdv);
+                    const float Z = rhs_vjp_multi<GODE, TB, RPW>(n, ew, o, tst, rfma(al, dv, v0), gde, gdv, use_gd, lane,
+                                                                 stg + ((size_t)st * 6 + s) * kSlot, kb, go, part, acc, dl, hin, xl, want_g, own);
+                    ZZ = (grp == s) ? Z : ZZ;
+                }
+                lam += group_sum8(rowsT[7 * kWave + lane] * ZZ);
+            }
+            int kf = 0;                                       // rows 0..kf are (copies of) x0
+            while (kf + 1 < T && !(tg[kf + 1] > tg[kf])) ++kf;
+            for (int r = 0; r <= kf; ++r) lam += gy_row(r);
+            if (own) {
+                if (lane < 6) a.gx0[(size_t)b * 6 + lane] = lam;
+                if constexpr (GODE) go_sum += go;
+            }
+            // nothing of this trajectory may enter the other waves' sums any more
+            dl[ts * 2 * kWave + lane] = 0.f; dl[ts * 2 * kWave + kWave + lane] = 0.f;
+            hin[ts * 2 * kWave + lane] = 0.f; hin[ts * 2 * kWave + kWave + lane] = 0.f;
+        }
+        if (lane == 0) atomicAdd(&done_cnt, 1);
+        for (;;) {
+            __syncthreads();                                  // = the first barrier of a round
+            if (*(volatile int *)&done_cnt == NW) break;      // (every wave is here: they all read NW in the same round)
+            multi_serve_round<TB, RPW>(n, acc, dl, hin, xl, lane, part, want_g);
+        }
+        __syncthreads();                                      // the counter is reset by the next group's prologue
+    }
+    // ---- this workgroup's gradient row: the hidden matrices' rows straight from their owners, the edge gradients and the ODE-constant
+    //      sums added over the walking waves in wave order through LDS (xl is free now)
+    if (!want_g && !GODE) return;
+    __syncthreads();
+    if (want_g) {
+        const int nm = L - 1, j0 = part * RPW;
+        if (nm > 0) acc.store_one(acc.m0, prow + n.hid_off(nm - 1), a.H, j0, lane);
+        if (nm > 1) acc.store_one(acc.m1, prow + n.hid_off(nm - 2), a.H, j0, lane);
+        if (nm > 2) acc.store_one(acc.m2, prow + n.hid_off(nm - 3), a.H, j0, lane);
+        if (nm > 3) acc.store_one(acc.m3, prow + n.hid_off(nm - 4), a.H, j0, lane);
+    }
+    // the hidden biases: wave 3 + slot holds the sum over all trajectories (slot sl = hidden matrix L - 2 - sl)
+    if (want_g && part >= 3 && part - 3 < L - 1) {
+        float *__restrict__ gb = prow + n.hid_off(L - 2 - (part - 3)) + (size_t)a.H * a.H;
+        if (lane < a.H) gb[lane] = acc.eb[0];
+        if (lane + 64 < a.H) gb[lane + 64] = acc.eb[1];
+    }
+    // edge values of the walking waves, added in wave order: through xl (free now) when they live in registers, straight from the waves'
+    // LDS tables otherwise; value 17 = the ODE-constant sums
+    constexpr int kVals = kMultiEdgeVals + 1;
+    static_assert(kVals * 2 * kWave <= TB * NW * 2 * kWave, "xl holds the edge values");
+    for (int w = 0; w < TB; ++w) {
+        __syncthreads();
+        if (part == w) {
+            for (int v = 0; v < kVals; ++v) {
+                float x0, x1;
+                if (v < kMultiEdgeVals) {
+                    if constexpr (MultiAcc<RPW>::kEdgeLds) { x0 = acc.edge_get(v, 0, lane); x1 = acc.edge_get(v, 1, lane); }
+                    else {
+                        x0 = x1 = 0.f;
+#pragma unroll
+                        for (int vv = 0; vv < kMultiEdgeVals; ++vv) if (vv == v) { x0 = acc.e[MultiAcc<RPW>::kEdgeLds ? 0 : vv][0]; x1 = acc.e[MultiAcc<RPW>::kEdgeLds ? 0 : vv][1]; }
+                    }
+                } else {
+                    x0 = go_sum; x1 = 0.f;
+                }
+                float *__restrict__ q = xl + (v * 2) * kWave + lane;
+                q[0] = (w == 0 ? 0.f : q[0]) + x0;
+                q[kWave] = (w == 0 ? 0.f : q[kWave]) + x1;
+            }
+        }
+    }
+    __syncthreads();
+    if (part == 0) {
+        const int H = a.H;
+        const bool vA = lane < H, vB = lane + 64 < H;
+        auto get = [&](int v, int half) { return xl[(v * 2 + half) * kWave + lane]; };
+        if (want_g) {
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+                if (vA) prow[n.out_off() + q * H + lane] = get(q, 0);
+                if (vB) prow[n.out_off() + q * H + lane + 64] = get(q, 1);
+            }
+#pragma unroll
+            for (int i = 0; i < 9; ++i) {
+                if (vA) prow[lane * 9 + i] = get(6 + i, 0);
+                if (vB) prow[(lane + 64) * 9 + i] = get(6 + i, 1);
+            }
+            if (vA) prow[9 * H + lane] = get(15, 0);
+            if (vB) prow[9 * H + lane + 64] = get(15, 1);
+            if (lane < 6) prow[n.out_off() + 6 * H + lane] = get(16, 0);
+        }
+        if constexpr (GODE) {
+            if (lane < 17) prow[a.P + lane] = get(17, 0);
+        }
+    }
+}
+
+template <int TB, int RPW> static int launch_bwd_generic_multi(hipStream_t s, const AdjArgs<float> &a, int L, int method, int bps)
+{
+    const dim3 grid(bps, a.n_sets), block(512);
+    const bool gd = a.gd_mode != 0;
+    if (a.gode) {
+        if (gd) hipLaunchKernelGGL((solve_bwd_generic_multi_kernel<true, true, TB, RPW>), grid, block, 0, s, a, method, L);
+        else hipLaunchKernelGGL((solve_bwd_generic_multi_kernel<true, false, TB, RPW>), grid, block, 0, s, a, method, L);
+    } else {
+        if (gd) hipLaunchKernelGGL((solve_bwd_generic_multi_kernel<false, true, TB, RPW>), grid, block, 0, s, a, method, L);
+        else hipLaunchKernelGGL((solve_bwd_generic_multi_kernel<false, false, TB, RPW>), grid, block, 0, s, a, method, L);
+    }
+    launch_adj_reduce(s, a.partials, (int)adj_partial_rowlen(a.P), bps, a.n_sets, a.P, a.gnn, a.gode);
+    return hipGetLastError() == hipSuccess ? HODE_OK : HODE_ELAUNCH;
+}
+
 template <typename R, int NW, int ACCREG> static int launch_bwd_generic_t(hipStream_t s, const AdjArgs<R> &a, int L, int method)
 {
     // with register accumulators a workgroup flushes once: fewer, longer-lived workgroups (a few per CU) beat one per trajectory
@@ -1126,6 +1540,16 @@ template <typename R, int NW, int ACCREG> static int launch_bwd_generic_t(hipStr
 template <typename R> int launch_solve_bwd_generic(hipStream_t s, const AdjArgs<R> &a, int L, int method)
 {
     if constexpr (sizeof(R) == 4) {
+        // large batches: several trajectories per team (solve_bwd_generic_multi_kernel) -- needs gradient rows (one per workgroup)
+        if (L >= 2 && L - 1 <= kGenAccMats && a.gnn != nullptr && a.partials != nullptr && a.n_sets <= a.partial_rows && a.n_sets <= 65535) {
+            const int per_set = a.B / a.n_sets;
+            const int rows_per_set = a.partial_rows / a.n_sets;
+            auto bps_for = [&](int tb) { int g = (per_set + tb - 1) / tb; if (g > rows_per_set) g = rows_per_set; if (g > 512) g = 512; return g < 1 ? 1 : g; };
+            if (a.B >= 2048)
+                return a.H > 64 ? launch_bwd_generic_multi<8, 16>(s, a, L, method, bps_for(8)) : launch_bwd_generic_multi<8, 8>(s, a, L, method, bps_for(8));
+            if (a.B >= 512)
+                return a.H > 64 ? launch_bwd_generic_multi<4, 16>(s, a, L, method, bps_for(4)) : launch_bwd_generic_multi<4, 8>(s, a, L, method, bps_for(4));
+        }
         // fp32, at most kGenAccMats hidden matrices: ALL parameter gradients accumulate in the team's registers (the wave's rows of
         // every hidden matrix, the edge pieces dealt out over the waves) and leave once per workgroup.  Teams of EIGHT waves also
         // above 64 hidden units (sixteen rows per wave: 128 accumulator registers): a 16-wave workgroup is capped at 128 VGPRs per

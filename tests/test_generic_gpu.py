@@ -316,7 +316,7 @@ def test_model_with_a_tanh_residual_trains_through_the_class_surface(golden_dir)
         bad.forward(x0, tt, ext)
 
 
-@pytest.mark.parametrize("H,L,B,n_sets", [(128, 5, 96, 1), (64, 5, 40, 1), (100, 2, 24, 3), (128, 5, 2100, 1)])
+@pytest.mark.parametrize("H,L,B,n_sets", [(128, 5, 96, 1), (64, 5, 40, 1), (100, 2, 24, 3), (128, 5, 2100, 1), (64, 5, 640, 2), (96, 3, 1030, 1)])
 def test_generic_adjoint_is_bit_reproducible_and_matches_the_oracle(hode, g0, H, L, B, n_sets):
     """Round 4 (VERDICT r3 missing 3): networks beyond 64 x 4 -- configs/ablation_no_physics.yaml trains 128 x 5 -- leave their
     parameter gradients as one row per workgroup + a fixed-order reduction, like the tuned path: the same bits run to run
@@ -357,3 +357,34 @@ def test_generic_adjoint_is_bit_reproducible_and_matches_the_oracle(hode, g0, H,
         assert np.max(np.abs(k[2].view(n_sets, 17)[s].cpu().numpy() - ro)) < 5e-3 * np.max(np.abs(ro))
         others = [q for q in range(n_sets) if q != s]
         assert all(float(k[1].view(n_sets, P)[q].abs().max()) == 0.0 for q in others)
+
+
+@pytest.mark.parametrize("H,L,B", [(128, 3, 1030), (40, 4, 2050)])
+def test_teams_that_walk_several_tapes_equal_the_one_trajectory_teams(hode, g0, H, L, B):
+    """Above 512 trajectories a team of the generic adjoint walks 4 or 8 tapes at once (solve_bwd_generic_multi_kernel): tapes of
+    DIFFERENT lengths (tight tolerances: the step count follows each patient's meals; a few trajectories starved of steps), a batch
+    that does not fill its last team.  Against the same trajectories through the one-trajectory teams, 400 at a time."""
+    import bench
+    T = 25
+    x0, t, meal, tv = bench.synth_cohort(B, 33)
+    x0 = (x0 * (0.6 + 0.8 * torch.rand(B, 6, generator=torch.Generator().manual_seed(1)))).cuda()
+    t, meal, tv = t[:T].cuda() * 3.0, meal[:, :T].contiguous().cuda(), tv[:, :T].contiguous().cuda()
+    nn, ode = torch.as_tensor(net(H, L, seed=5), dtype=torch.float32).cuda(), torch.as_tensor(g0["ode"], dtype=torch.float32).cuda()
+    probe = hode.solve_fwd(x0, t, meal, tv, None, ode, nn, H, L, rtol=1e-7, atol=1e-9, max_steps=200)
+    budget = int(np.percentile(probe.nsteps.cpu().numpy(), 80))          # a fifth of the trajectories runs out of steps: status 1, short tape
+    sol = hode.solve_fwd(x0, t, meal, tv, None, ode, nn, H, L, rtol=1e-7, atol=1e-9, want_tape=True, max_steps=budget)
+    ns = sol.nsteps.cpu().numpy()
+    assert len(set(ns.tolist())) > 3 and int((sol.status != 0).sum()) > 0 and int((sol.status == 0).sum()) > B // 2, (set(ns.tolist()), sol.status.unique())
+    gy = torch.randn(B, T, 6, device="cuda", generator=torch.Generator("cuda").manual_seed(4)) / (B * T)
+    gx0, gnn, gode = hode.solve_bwd(sol, gy, want_gode=True)
+    rx, rn, ro = [], 0.0, 0.0
+    for lo in range(0, B, 400):
+        sl = slice(lo, min(lo + 400, B))
+        part = hode.solve_fwd(x0[sl].contiguous(), t, meal[sl].contiguous(), tv[sl].contiguous(), None, ode, nn, H, L, rtol=1e-7, atol=1e-9,
+                              want_tape=True, max_steps=budget)
+        assert torch.equal(part.y, sol.y[sl]) and torch.equal(part.nsteps, sol.nsteps[sl])
+        px, pn, po = hode.solve_bwd(part, gy[sl].contiguous(), want_gode=True)
+        rx.append(px); rn = rn + pn.double(); ro = ro + po.double()
+    rx = torch.cat(rx)
+    assert torch.isfinite(gnn).all() and relnorm(gx0.cpu().numpy(), rx.cpu().numpy()) < 1e-6
+    assert relnorm(gnn.cpu().numpy(), rn.cpu().numpy()) < 2e-5 and relnorm(gode.cpu().numpy(), ro.cpu().numpy()) < 2e-5
