@@ -62,3 +62,9 @@ for name, d in seg.items():
         print(f"  {name}: mean {d.mean():7.0f}  min {d.min():6d}  p90 {np.percentile(d, 90):7.0f}")
     tot += d.mean()
 print(f"  total per evaluation {tot:.0f} cycles  (x 1448 evaluations = {tot * 1448 / 1e6:.2f} M cycles per trajectory)")
+# evaluation-to-evaluation time along the trajectory (deciles): is the wave slower at the start or the end of the launch?
+ent = rec[:, 0]
+d = np.diff(ent)
+d = d[d < 20000]
+dec = np.array_split(d, 10)
+print("  entry-to-entry cycles by decile of the trajectory:", [int(x.mean()) for x in dec])
