@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Soak test of the generic path's multi-trajectory teams (every wave of a team must reach every barrier whatever the step counts,
+statuses, shapes and batch sizes are): random shapes / batches / parameter sets / tolerances / step budgets for N seconds; every
+case runs forward with tape + adjoint twice and checks finiteness, run-to-run bit equality and the trajectories against the
+one-trajectory teams (launches of <= 400).  Run under `timeout`: a hang IS the failure it looks for.   python tools/soak_generic.py 120"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "hybrid-ode-for-glp-1-and-glucose_amd")); sys.path.insert(0, ROOT)
+import numpy as np, torch, hode, bench
+dev = torch.device("cuda")
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+t_end, n = time.time() + budget, 0
+while time.time() < t_end:
+    H = int(rng.choice([7, 33, 40, 64, 65, 96, 100, 128])); L = int(rng.integers(2, 6)); T = int(rng.choice([9, 25, 61]))
+    n_sets = int(rng.choice([1, 1, 2, 3, 8])); per = int(rng.integers(130, 1400) if n_sets == 1 else rng.integers(40, 400))
+    if rng.random() < 0.5: per = (per + 7) // 8 * 8
+    B = per * n_sets
+    rtol = float(rng.choice([1e-4, 1e-6, 1e-8])); gode = bool(rng.random() < 0.5)
+    g = torch.Generator().manual_seed(int(rng.integers(1 << 30)))
+    P = hode.n_params(H, L)
+    nn = (torch.randn(n_sets * P, generator=g) * (0.5 * (2.0 / (2 * H)) ** 0.5)).to(dev)
+    ode = bench.ODE_DEFAULT.repeat(n_sets).to(dev)
+    x0, t, meal, tv = bench.synth_cohort(B, int(rng.integers(1000)))
+    x0 = (x0 * (0.5 + torch.rand(B, 6, generator=g))).to(dev)
+    if rng.random() < 0.2: x0[int(rng.integers(B))] = float("nan")
+    t, meal, tv = (t[:T] * float(rng.choice([1.0, 3.0]))).to(dev), meal[:, :T].contiguous().to(dev), tv[:, :T].contiguous().to(dev)
+    probe = hode.solve_fwd(x0, t, meal, tv, None, ode, nn, H, L, rtol=rtol, atol=rtol * 1e-2, n_sets=n_sets, max_steps=400)
+    ms = int(np.percentile(probe.nsteps.cpu().numpy(), float(rng.choice([60, 90, 100])))) + int(rng.integers(0, 3))
+    ms = max(ms, T - 1)
+    sol = hode.solve_fwd(x0, t, meal, tv, None, ode, nn, H, L, rtol=rtol, atol=rtol * 1e-2, n_sets=n_sets, want_tape=True, max_steps=ms)
+    gy = torch.randn(B, T, 6, device=dev, generator=torch.Generator(dev).manual_seed(n)) / (B * T)
+    a = hode.solve_bwd(sol, gy, want_gode=gode)
+    b = hode.solve_bwd(sol, gy, want_gode=gode)
+    ok_rows = sol.status == 0
+    assert torch.isfinite(sol.y[ok_rows]).all()
+    for u, v in zip(a, b):
+        if u is not None:
+            assert torch.equal(u, v), ("not reproducible", H, L, T, B, n_sets)
+    assert torch.isfinite(a[1]).all(), ("gnn not finite", H, L, T, B, n_sets, int((sol.status != 0).sum()))
+    lo = int(rng.integers(0, per - 20)); sl = slice(lo, lo + min(400, per - lo))
+    small = hode.solve_fwd(x0[sl].contiguous(), t, meal[sl].contiguous(), tv[sl].contiguous(), None, ode[:17], nn[:P], H, L, rtol=rtol,
+                           atol=rtol * 1e-2, want_tape=True, max_steps=ms)
+    assert torch.equal(small.y.nan_to_num(), sol.y[sl].nan_to_num()) and torch.equal(small.status, sol.status[sl]), ("forward differs", H, L, T, B, n_sets)
+    n += 1
+    print(f"case {n}: H={H} L={L} T={T} B={B} sets={n_sets} rtol={rtol:g} max_steps={ms} failed={int((sol.status != 0).sum())} gode={gode} ok", flush=True)
+torch.cuda.synchronize()
+print(f"{n} cases, no hang, no mismatch")
