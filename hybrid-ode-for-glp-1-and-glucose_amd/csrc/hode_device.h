@@ -570,6 +570,12 @@ template <bool RELU> __device__ __forceinline__ float mlp_hidden_blk(const f2_t 
 {
     // accumulator pairs (a0, a2) and (a1, a3): after the two 16-lane swaps the sums a0 + a1 and a2 + a3 are ONE packed add
     f2_t a02, a13, hr;
+    // h is a FRESH vector result (the previous layer's v_max) and a DPP read needs two wait states behind its producer.  The two
+    // products of rotation 0 used to BE those wait states -- by source order; but a DPP move depends on h only, and in some
+    // instantiations (RK4 x three layers x tape) hipcc scheduled moves in front of the products: stale lanes, trajectories off by
+    // 1e-1, silently (found by tools/soak_tuned.py, pinned down and now checked by tools/dpp_hazard_check.py).  So every reader of h
+    // takes it from this statement: two wait states, one issue slot, and the moves stay free to be scheduled early.
+    asm("s_nop 1" : "+v"(h));
 #ifndef HODE_BLK_UNPINNED
     // The accumulators live in v[4:7] BY NAME (constraint {v[..]} on every statement of the layer, so that the register
     // allocator keeps them there from the first product to the last swap): the finish can then swap HALVES of the pairs and add

@@ -707,3 +707,32 @@ np.savez({out!r}, gx0=gx0.cpu().numpy(), gnn=gnn.cpu().numpy(), gode=gode.cpu().
     c = torch.randn(42, 61, 6, device="cuda", generator=torch.Generator("cuda").manual_seed(4)).cpu().numpy()[:21]
     rx, rnn, rode = O.solve_bwd(ref, c.astype(np.float64))
     assert relnorm(a["gnn"][:13510], rnn) < 1e-4 and relnorm(a["gx0"][:21], rx) < 1e-4 and relnorm(a["gode"][:17], rode) < 1e-3
+
+
+@pytest.mark.parametrize("method", ["dp54", "rk4"])
+@pytest.mark.parametrize("H,L", [(64, 1), (64, 2), (64, 3), (33, 3), (64, 4), (16, 4)])
+def test_every_forward_instantiation_tapes_what_it_would_have_returned(hode, g0, H, L, method):
+    """The taping and the plain instantiation of the forward kernel are different code (template parameters NL, METHOD, TAPE): the
+    same trajectories bit for bit, the same status / step counts, and the fp32 oracle's answer -- for every depth and both
+    methods.  Round 4's soak test found RK4 x three layers x tape returning trajectories that were 1e-1 off (a DPP read scheduled
+    one instruction behind its producer in that instantiation only: tools/dpp_hazard_check.py); nothing in the suite had compared
+    the fp32 RK4 taping kernel's TRAJECTORIES with anything."""
+    import bench
+    T, B = 13, 40
+    gen = torch.Generator().manual_seed(1)
+    nn = (torch.randn(O.n_params(H, L), generator=gen) * (0.7 * (2.0 / (2 * H)) ** 0.5)).cuda()
+    ode = torch.as_tensor(g0["ode"], dtype=torch.float32).cuda()
+    x0, t, meal, tv = bench.synth_cohort(B, 5)
+    x0, t, meal, tv = x0.cuda(), t[:T].contiguous().cuda(), meal[:, :T].contiguous().cuda(), tv[:, :T].contiguous().cuda()
+    m = hode.METHOD_RK4 if method == "rk4" else hode.METHOD_DP54
+    plain = hode.solve_fwd(x0, t, meal, tv, None, ode, nn, H, L, method=m, max_steps=40)
+    taped = hode.solve_fwd(x0, t, meal, tv, None, ode, nn, H, L, method=m, max_steps=40, want_tape=True)
+    assert torch.equal(plain.y, taped.y) and torch.equal(plain.status, taped.status) and torch.equal(plain.nsteps, taped.nsteps)
+    ref = O.solve(x0.cpu().numpy(), t.cpu().numpy(), meal.cpu().numpy(), tv.cpu().numpy(), None, ode.cpu().numpy(), nn.cpu().numpy(), H, L,
+                  method=(O.METHOD_RK4 if method == "rk4" else O.METHOD_DP54), dtype=np.float32, max_steps=40)
+    assert int(plain.status.max()) == 0
+    if method == "rk4":
+        assert np.array_equal(plain.nsteps.cpu().numpy(), ref.nsteps)
+    # (adaptive: a borderline accept may fall the other way between the kernel's and the oracle's fp32 arithmetic -- +-1 step on a few
+    #  trajectories of this randomly initialised network; the values agree to the tolerance either way)
+    assert np.max(np.abs(plain.y.cpu().numpy() - ref.y) / (np.abs(ref.y) + 1e-2)) < (2e-5 if method == "rk4" else 2e-4)

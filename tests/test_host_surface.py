@@ -389,3 +389,20 @@ def test_product_library_carries_no_experiment_kernels_and_no_env_dispatch():
         assert "launch_solve_fwd_wg" in lsyms and "launch_solve_bwd_split" in lsyms
         for name in hode.capi.SYMBOLS:                            # the lab library is the same C ABI
             assert name in lsyms, name
+
+
+def test_no_dpp_read_sits_closer_than_two_wait_states_behind_its_producer():
+    """tools/dpp_hazard_check.py on the two sources whose hot loops are inline asm (cross-compiles for gfx950, no GPU needed): hipcc
+    does not look inside asm statements and may re-order independent ones; a DPP / lane-swap read of a register one instruction
+    after the vector instruction that wrote it returns stale lanes -- silently, and only in the instantiations where the
+    scheduler happened to do it (round 4: RK4 x three layers x tape)."""
+    import shutil
+    import subprocess
+    import sys
+    if shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "hybrid-ode-for-glp-1-and-glucose_amd", "csrc")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "dpp_hazard_check.py"), os.path.join(csrc, "hode_solve_fwd.hip"),
+                        os.path.join(csrc, "hode_solve_bwd_ws.hip")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "0 hazard(s)" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
