@@ -15,7 +15,7 @@ cd /tmp
 # --no-zscore: every launch of solve_fwd_kernel<float,4,0,2,false,false> is then the benchmark workload (physio cohort,
 # 4 096 x 241), so the profile's average duration of that kernel IS bench.py's ms_per_step; the z-scored regime gets its own
 # trace below (same kernel name, other workload: 3.7-3.9 ms)
-ARGS="--steps 5 --warmup 2 --train-steps 2 --no-cpu-baseline --no-vi --no-generic --no-zscore --no-sobol --no-class-path --no-build"
+ARGS="--steps 12 --warmup 3 --train-steps 12 --no-cpu-baseline --no-vi --no-generic --no-zscore --no-sobol --no-class-path --no-build"
 # the kernel sources these counters belong to (bench.py reports PMC traffic only while this hash matches)
 python3 -c "import sys; sys.path.insert(0, '$R'); import bench; print(bench.kernel_source_sha())" > $OUT/kernel_source_sha.txt
 # the trace pass runs 40 + 5 forward launches and 20 training steps: the first launches of a process are slower (clocks, cold

@@ -22,3 +22,4 @@ print("forward %.3f ms  %.0f traj/s  frac %.3f  traffic %s" % (d["ms_per_step"],
 print("train step %.2f ms  adjoint %.2f ms  forward+tape %.2f ms" % (t["ms_per_step"], t["roofline"]["adjoint"]["kernel_ms"], t["roofline"]["forward_with_tape"]["kernel_ms"]))
 PY
 python tools/fill_design.py $TAG
+python tools/fill_readme.py $TAG > /dev/null

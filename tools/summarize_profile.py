@@ -48,7 +48,7 @@ for fcsv in glob.glob(os.path.join(src, "pmc_*", "*", "*_counter_collection.csv"
             for c, v in d.items():
                 pmc[k][c] = sum(v) / len(v)
             pmc[k].setdefault("_launches", len(next(iter(d.values()))))
-out = {"command": "rocprofv3 --pmc <group> -- python3 bench.py --steps 5 --warmup 2 --train-steps 2 --no-cpu-baseline",
+out = {"command": "rocprofv3 --pmc <group> -- python3 bench.py --steps 12 --warmup 3 --train-steps 12 --no-cpu-baseline ...",
        "note": "per-launch averages; one rocprofv3 run per counter group (FETCH_SIZE and WRITE_SIZE in separate passes)",
        "kernels": pmc}
 traffic = {}
