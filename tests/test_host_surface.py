@@ -392,7 +392,7 @@ def test_product_library_carries_no_experiment_kernels_and_no_env_dispatch():
 
 
 def test_no_dpp_read_sits_closer_than_two_wait_states_behind_its_producer():
-    """tools/dpp_hazard_check.py on the two sources whose hot loops are inline asm (cross-compiles for gfx950, no GPU needed): hipcc
+    """tools/dpp_hazard_check.py (DPP / lane-swap reads behind their producers; LDS results named before their wait) on the two sources whose hot loops are inline asm (cross-compiles for gfx950, no GPU needed): hipcc
     does not look inside asm statements and may re-order independent ones; a DPP / lane-swap read of a register one instruction
     after the vector instruction that wrote it returns stale lanes -- silently, and only in the instantiations where the
     scheduler happened to do it (round 4: RK4 x three layers x tape)."""
@@ -403,6 +403,26 @@ def test_no_dpp_read_sits_closer_than_two_wait_states_behind_its_producer():
         pytest.skip("no hipcc")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     csrc = os.path.join(root, "hybrid-ode-for-glp-1-and-glucose_amd", "csrc")
+    # the checker itself: a kernel with one hazard of each class it knows (a DPP read right behind its producer; an LDS result named
+    # before its wait) must be reported
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        bad = os.path.join(tmp, "bad.hip")
+        open(bad, "w").write('''#include <hip/hip_runtime.h>
+__global__ void bad_kernel(float *out, const float *in)
+{
+    __shared__ float sm[64];
+    sm[threadIdx.x] = in[threadIdx.x];
+    __syncthreads();
+    float a = in[threadIdx.x + 64], r, c, q, z;
+    asm volatile("v_add_f32 %0, %1, %1\\n\\tv_mov_b32_dpp %2, %0 row_ror:1 row_mask:0xf bank_mask:0xf" : "=&v"(r), "+v"(a), "=&v"(c));
+    unsigned addr = threadIdx.x * 4;
+    asm volatile("ds_read_b32 %0, %2\\n\\tv_add_f32 %1, %0, %0\\n\\ts_waitcnt lgkmcnt(0)" : "=&v"(q), "=&v"(z) : "v"(addr));
+    out[threadIdx.x] = r + c + q + z;
+}
+''')
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "dpp_hazard_check.py"), bad], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 1 and "2 hazard(s)" in r.stdout and "v_mov_b32_dpp" in r.stdout and "LDS read" in r.stdout, r.stdout + r.stderr
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "dpp_hazard_check.py"), os.path.join(csrc, "hode_solve_fwd.hip"),
                         os.path.join(csrc, "hode_solve_bwd_ws.hip")], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "0 hazard(s)" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

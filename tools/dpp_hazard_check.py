@@ -8,7 +8,12 @@ v_permlane16/32_swap) READS that VGPR through the cross-lane path.  hipcc's haza
 but does not look INSIDE inline asm, and independent asm statements may be re-ordered by the scheduler -- so a v_mov_b32_dpp that the
 source places two instructions behind its producer can end up right behind it in one instantiation and not in the next.  This script
 walks every kernel of the given sources (straight-line: a label resets the window, which can only miss, not invent, a hazard) and
-reports each DPP / swap read whose source register was written by a VALU instruction fewer than two wait states earlier."""
+reports each DPP / swap read whose source register was written by a VALU instruction fewer than two wait states earlier.
+
+Second check (the adjoint reads LDS through inline asm, with its own counted `s_waitcnt lgkmcnt(n)`, because hipcc would otherwise wait
+for every outstanding vector-memory operation in front of a read that may alias an LDS-DMA target): no instruction may name the
+destination registers of an LDS read before a wait has covered it -- hipcc does not know that the asm's outputs are not there yet and is
+free to copy them.  LDS operations return in order: `lgkmcnt(n)` leaves the last n of them pending."""
 import os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "hybrid-ode-for-glp-1-and-glucose_amd", "csrc")
@@ -35,18 +40,37 @@ for src in srcs:
                     "-Wno-unused-function", *flags, src if os.path.isabs(src) else os.path.join(ROOT, src), "-o", out], check=True,
                    stderr=subprocess.DEVNULL)
     kernel, window, nk = None, [], 0                    # window: [(written vgprs, wait states since)]
+    lds_q = []                                          # LDS operations in flight, in issue order: destination registers (empty for writes)
     for raw in open(out):
         line = raw.split(";")[0].strip()
         m = re.match(r"^(_Z\w+):", raw)
         if m:
-            kernel, window = m.group(1), []
+            kernel, window, lds_q = m.group(1), [], []
             continue
         if not line or line.startswith("."):
             if re.match(r"^\.LBB", raw):
-                window = []
+                window, lds_q = [], []
             continue
         parts = line.replace(",", " ").split()
         op, ops = parts[0], parts[1:]
+        # ---- LDS results named before their wait
+        if op == "s_waitcnt":
+            m2 = re.search(r"lgkmcnt\((\d+)\)", line)
+            if m2:
+                keep = int(m2.group(1))
+                lds_q = lds_q[len(lds_q) - keep:] if keep else []
+            elif "vmcnt" not in line and "expcnt" not in line:          # a numeric s_waitcnt: assume it waits for everything
+                lds_q = []
+        elif kernel and lds_q:
+            named = set().union(*(regs(o) for o in ops)) if ops else set()
+            for dst in lds_q:
+                if dst & named:
+                    total += 1
+                    print(f"{os.path.basename(src)}: {kernel}: `{line}` names v{sorted(dst & named)}, the destination of an LDS read no wait has covered yet")
+                    break
+        if op.startswith("ds_") or op.startswith("s_load") or op.startswith("s_buffer_load"):
+            is_read = op.startswith(("ds_read", "ds_swizzle", "ds_bpermute", "ds_permute", "ds_consume", "ds_append"))
+            lds_q.append(regs(ops[0]) if (is_read and ops) else set())
         ws = 1
         if op == "s_nop":
             ws = int(ops[0]) + 1
