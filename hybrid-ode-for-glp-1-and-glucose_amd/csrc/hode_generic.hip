@@ -936,17 +936,24 @@ template <typename R, int METHOD> static int launch_fwd_generic_m(hipStream_t s,
     // trajectory, the policy until now: 10.6 / 4.9); 4 096: 24.6 against 22.0 / 15.4 against 7.8.
     const bool narrow = a.H <= 64;
     if constexpr (sizeof(R) == 4) {
-        if (a.L >= 2 && a.L - 1 <= kGenAccMats && a.B <= (narrow ? 256 : 512))
-            return narrow ? launch_fwd_generic_t<R, METHOD, 8, 8, 1>(s, a) : launch_fwd_generic_t<R, METHOD, 8, 16, 2>(s, a);
-        // above that: several trajectories per team, rows still register-resident (four per team up to two workgroups per CU's worth of
-        // trajectories, eight beyond); needs whole parameter sets per workgroup
-        if (a.L >= 2 && a.L - 1 <= kGenAccMats) {
+        // up to one trajectory per CU's team: one trajectory per team.  Above: several per team, rows still register-resident -- the
+        // fewest per team (2, 4, 8) that put the batch on the chip in ONE round of 256 teams (768 trajectories as 384 teams of two: 4.0 +
+        // 8.0 ms; as 192 teams of four: 2.9 + 5.1); whole parameter sets per workgroup
+        if (a.L >= 2 && a.L - 1 <= kGenAccMats && a.B > 256) {
             const int per_set = a.B / a.n_sets;
-            if (a.B >= 2048 && per_set % 8 == 0)
+            if (a.B <= 512 && per_set % 2 == 0)
+                return narrow ? launch_fwd_generic_multi<METHOD, 2, 8, 1>(s, a) : launch_fwd_generic_multi<METHOD, 2, 16, 2>(s, a);
+            if (a.B <= 1024 && per_set % 4 == 0)
+                return narrow ? launch_fwd_generic_multi<METHOD, 4, 8, 1>(s, a) : launch_fwd_generic_multi<METHOD, 4, 16, 2>(s, a);
+            if (per_set % 8 == 0)
                 return narrow ? launch_fwd_generic_multi<METHOD, 8, 8, 1>(s, a) : launch_fwd_generic_multi<METHOD, 8, 16, 2>(s, a);
             if (per_set % 4 == 0)
                 return narrow ? launch_fwd_generic_multi<METHOD, 4, 8, 1>(s, a) : launch_fwd_generic_multi<METHOD, 4, 16, 2>(s, a);
+            if (per_set % 2 == 0)
+                return narrow ? launch_fwd_generic_multi<METHOD, 2, 8, 1>(s, a) : launch_fwd_generic_multi<METHOD, 2, 16, 2>(s, a);
         }
+        if (a.L >= 2 && a.L - 1 <= kGenAccMats && a.B <= (narrow ? 256 : 512))
+            return narrow ? launch_fwd_generic_t<R, METHOD, 8, 8, 1>(s, a) : launch_fwd_generic_t<R, METHOD, 8, 16, 2>(s, a);
     }
     if (a.B <= 256) return narrow ? launch_fwd_generic_t<R, METHOD, 8, 8, 0>(s, a) : launch_fwd_generic_t<R, METHOD, 8, 16, 0>(s, a);
     return narrow ? launch_fwd_generic_t<R, METHOD, 4, 8, 0>(s, a) : launch_fwd_generic_t<R, METHOD, 4, 16, 0>(s, a);
@@ -1325,7 +1332,8 @@ __global__ __launch_bounds__(512, 2) void solve_bwd_generic_multi_kernel(const A
     __shared__ float eld_all[(MultiAcc<RPW>::kEdgeLds ? TB : 1) * kMultiEdgeVals * 2 * kWave];     // the walking waves' edge sums (H > 64)
     __shared__ float edge_img[kEdgeImageMax];
     __shared__ float dl[TB * 2 * kWave], hin[TB * 2 * kWave];
-    __shared__ float xl[TB * NW * 2 * kWave];
+    constexpr int kXl = TB * NW * 2 * kWave > (kMultiEdgeVals + 1) * 2 * kWave ? TB * NW * 2 * kWave : (kMultiEdgeVals + 1) * 2 * kWave;
+    __shared__ float xl[kXl];                                  // partial sums [TB][NW][2][64]; at the end the edge values [18][2][64]
     __shared__ int done_cnt;
     const int lane = threadIdx.x & 63;
     const int part = first_lane((int)(threadIdx.x >> 6));
@@ -1440,7 +1448,7 @@ __global__ __launch_bounds__(512, 2) void solve_bwd_generic_multi_kernel(const A
     // edge values of the walking waves, added in wave order: through xl (free now) when they live in registers, straight from the waves'
     // LDS tables otherwise; value 17 = the ODE-constant sums
     constexpr int kVals = kMultiEdgeVals + 1;
-    static_assert(kVals * 2 * kWave <= TB * NW * 2 * kWave, "xl holds the edge values");
+    static_assert(kVals * 2 * kWave <= kXl, "xl holds the edge values");
     for (int w = 0; w < TB; ++w) {
         __syncthreads();
         if (part == w) {
@@ -1545,10 +1553,13 @@ template <typename R> int launch_solve_bwd_generic(hipStream_t s, const AdjArgs<
             const int per_set = a.B / a.n_sets;
             const int rows_per_set = a.partial_rows / a.n_sets;
             auto bps_for = [&](int tb) { int g = (per_set + tb - 1) / tb; if (g > rows_per_set) g = rows_per_set; if (g > 512) g = 512; return g < 1 ? 1 : g; };
-            if (a.B >= 2048)
+            // (the fewest trajectories per team that put the batch on the chip in one round: see launch_fwd_generic_m)
+            if (a.B > 1024)
                 return a.H > 64 ? launch_bwd_generic_multi<8, 16>(s, a, L, method, bps_for(8)) : launch_bwd_generic_multi<8, 8>(s, a, L, method, bps_for(8));
-            if (a.B >= 512)
+            if (a.B > 512)
                 return a.H > 64 ? launch_bwd_generic_multi<4, 16>(s, a, L, method, bps_for(4)) : launch_bwd_generic_multi<4, 8>(s, a, L, method, bps_for(4));
+            if (a.B > 256)
+                return a.H > 64 ? launch_bwd_generic_multi<2, 16>(s, a, L, method, bps_for(2)) : launch_bwd_generic_multi<2, 8>(s, a, L, method, bps_for(2));
         }
         // fp32, at most kGenAccMats hidden matrices: ALL parameter gradients accumulate in the team's registers (the wave's rows of
         // every hidden matrix, the edge pieces dealt out over the waves) and leave once per workgroup.  Teams of EIGHT waves also
