@@ -359,7 +359,7 @@ def test_generic_adjoint_is_bit_reproducible_and_matches_the_oracle(hode, g0, H,
         assert all(float(k[1].view(n_sets, P)[q].abs().max()) == 0.0 for q in others)
 
 
-@pytest.mark.parametrize("H,L,B", [(128, 3, 1030), (40, 4, 2050)])
+@pytest.mark.parametrize("H,L,B", [(128, 3, 1030), (40, 4, 2050), (96, 3, 402), (64, 5, 700)])      # teams of 8, 8, 2 and 4 trajectories
 def test_teams_that_walk_several_tapes_equal_the_one_trajectory_teams(hode, g0, H, L, B):
     """Above 512 trajectories a team of the generic adjoint walks 4 or 8 tapes at once (solve_bwd_generic_multi_kernel): tapes of
     DIFFERENT lengths (tight tolerances: the step count follows each patient's meals; a few trajectories starved of steps), a batch
@@ -378,8 +378,8 @@ def test_teams_that_walk_several_tapes_equal_the_one_trajectory_teams(hode, g0, 
     gy = torch.randn(B, T, 6, device="cuda", generator=torch.Generator("cuda").manual_seed(4)) / (B * T)
     gx0, gnn, gode = hode.solve_bwd(sol, gy, want_gode=True)
     rx, rn, ro = [], 0.0, 0.0
-    for lo in range(0, B, 400):
-        sl = slice(lo, min(lo + 400, B))
+    for lo in range(0, B, 250):                       # (<= 256: the one-trajectory teams)
+        sl = slice(lo, min(lo + 250, B))
         part = hode.solve_fwd(x0[sl].contiguous(), t, meal[sl].contiguous(), tv[sl].contiguous(), None, ode, nn, H, L, rtol=1e-7, atol=1e-9,
                               want_tape=True, max_steps=budget)
         assert torch.equal(part.y, sol.y[sl]) and torch.equal(part.nsteps, sol.nsteps[sl])
